@@ -1,0 +1,104 @@
+/*
+ * rmgr/ssim-hip.h -- the C ABI of the MI355X (gfx950) SSIM engine.
+ *
+ * This is the drop-in boundary: plain C, pointers and sizes only, no HIP / torch / C++ types.
+ * <rmgr/ssim.h>'s entry points are thin C++98 wrappers over it (ssim_amd/csrc/ssim_dropin.cpp),
+ * and any other host (ctypes, cgo, JNI ...) binds these symbols directly -- see INTEGRATION.md.
+ *
+ * Each function names the reference interface it stands in for (file:line in romigrou/ssim):
+ *
+ *   rmgr_ssim_hip_compute_ssim_host    rmgr::ssim::compute_ssim           src/ssim.cpp:933-1106
+ *   rmgr_ssim_hip_compute_ssim_device  same, images/map already in HBM    src/ssim.cpp:933-1106
+ *   rmgr_ssim_hip_enqueue_batch        the caller-side loop over pairs    src/ssim-cli.cpp:197-210
+ *                                      + per-thread fp64 partials         src/ssim.cpp:902-926
+ *   rmgr_ssim_hip_finalize             the final mean                     src/ssim.cpp:1090-1103
+ *   rmgr_ssim_hip_set_mode             select_impl() / RMGR_SSIM_USE_DOUBLE   src/ssim.cpp:808-896, src/ssim_internal.h:26-37
+ *
+ * All functions return 0 or an errno value (EINVAL, ENOMEM, ECHILD = a HIP call failed,
+ * ENODEV = no gfx950 device / extension not usable), exactly like the reference's API.
+ */
+#ifndef RMGR_SSIM_HIP_H
+#define RMGR_SSIM_HIP_H
+
+#include <rmgr/ssim.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Arithmetic of the blur + SSIM stage. */
+#define RMGR_SSIM_HIP_MODE_EXACT   0  /* operation order of the reference's FMA path (src/ssim_fma.cpp:196-257,
+                                         src/ssim_avx.cpp:342-352): bit-identical per-pixel results. Default. */
+#define RMGR_SSIM_HIP_MODE_FAST    1  /* separable 11+11 fp32 blur; within the documented tolerance, not bit-identical */
+#define RMGR_SSIM_HIP_MODE_DOUBLE  2  /* RMGR_SSIM_USE_DOUBLE semantics: fp64 internals, true double kernel (tests/ssim_naive.h) */
+#define RMGR_SSIM_HIP_MODE_UNFUSED 3  /* operation order of the reference's AVX/SSE/generic paths (mul and add rounded separately) */
+
+typedef struct rmgr_ssim_hip_Context_ rmgr_ssim_hip_Context;
+
+/* Number of usable HIP devices (0 when none; never fails). */
+rmgr_int32_t rmgr_ssim_hip_get_device_count(rmgr_int32_t* count) RMGR_NOEXCEPT;
+
+/* Creates an engine bound to `device`.  `stream` is a hipStream_t passed as void* (NULL: the
+ * context creates and owns a non-blocking stream).  All work of the context is ordered on it. */
+rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** ctx, rmgr_int32_t device, void* stream) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
+rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mode) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
+
+/* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the
+ * kernel variant.  Results do not depend on either (tests/test_gpu_parity.py checks). */
+rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT;
+
+/*
+ * compute_ssim() on HOST pointers: stages both images to HBM, runs the kernels, copies the map
+ * back (any ssimStep/ssimStride), returns the global SSIM.  Validation and return codes are the
+ * reference's (src/ssim.cpp:962-978).  ctx may be NULL: a process-wide default context on
+ * device 0 (or $RMGR_SSIM_HIP_DEVICE) is used under a lock.
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* ctx, float* ssim, const rmgr_ssim_Params* params,
+                                             const rmgr_ssim_ThreadPool* threadPool) RMGR_NOEXCEPT;
+
+/*
+ * Same computation with imgA.topLeft, imgB.topLeft and ssimMap being DEVICE pointers (step/stride
+ * semantics unchanged).  `ssim` is a host pointer; the call returns after the result is there.
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* ctx, float* ssim, const rmgr_ssim_Params* params) RMGR_NOEXCEPT;
+
+/*
+ * Asynchronous batch: `count` pairs of identical width/height, all pointers device-resident.
+ * One launch covers the whole batch; image i's fp64 sum of per-pixel SSIM values is written to
+ * sumsDevice[i] (device memory, count doubles) in a fixed reduction order, so the value does not
+ * depend on how a batch is split across calls, contexts or GPUs.  Returns once enqueued.
+ */
+rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
+                                         double* sumsDevice) RMGR_NOEXCEPT;
+
+/* ssim[i] = float(sums[i] / double(width*height)) with the reference's 32-bit product (src/ssim.cpp:1102).  Host arrays. */
+rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT;
+
+/* Blocks until everything enqueued on the context's stream has finished. */
+rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
+/* Device memory for hosts that have no HIP runtime of their own. */
+rmgr_int32_t rmgr_ssim_hip_malloc(rmgr_ssim_hip_Context* ctx, void** devicePtr, size_t size) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_free(rmgr_ssim_hip_Context* ctx, void* devicePtr) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_memcpy_h2d(rmgr_ssim_hip_Context* ctx, void* devicePtr, const void* hostPtr, size_t size) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* ctx, void* hostPtr, const void* devicePtr, size_t size) RMGR_NOEXCEPT;
+
+/*
+ * Kernel timing with HIP events on the context's stream.  While enabled, every launch of the
+ * main SSIM kernel is bracketed by an event pair; get_profile() (after a synchronize) returns
+ * how many launches were timed and their summed duration in milliseconds, then resets.
+ */
+rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* ctx, rmgr_int32_t enabled) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* ctx, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT;
+
+/* Human-readable description of the device and build ("gfx950 ... CUs ..."); static storage. */
+const char* rmgr_ssim_hip_describe(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* RMGR_SSIM_HIP_H */

@@ -1,0 +1,10 @@
+"""ssim_amd -- MI355X-native SSIM engine, drop-in for rmgr::ssim::compute_ssim (romigrou/ssim 2.1.0).
+
+The product is the C/C++ library ssim_amd/lib/librmgr-ssim-hip.so (sources in ssim_amd/csrc,
+public headers in include/rmgr).  This Python package only binds its C ABI for tests and bench.py.
+"""
+from .api import (  # noqa: F401
+    C_SYMBOLS, CXX_SYMBOLS, LIB_PATH, MODE_DOUBLE, MODE_EXACT, MODE_FAST, MODE_UNFUSED,
+    Context, DeviceBuffer, ImgParams, Params, SsimError, ThreadPool, Version,
+    compute_ssim, device_count, finalize, get_version, load_library, make_params,
+)

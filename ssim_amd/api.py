@@ -1,0 +1,288 @@
+"""ctypes binding of the C ABI in include/rmgr/ssim-hip.h and include/rmgr/ssim.h.
+
+This module is plumbing for tests and bench.py: the product is the shared library
+(ssim_amd/lib/librmgr-ssim-hip.so) and its C/C++ headers.  Struct layouts mirror
+include/rmgr/ssim.h field for field (reference include/rmgr/ssim.h:469-533).
+
+There is no fallback of any kind: if the library is missing, or no gfx950 device is usable,
+calls raise (ImportError / SsimError with the errno the C ABI returned).
+"""
+import ctypes
+import errno
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librmgr-ssim-hip.so")
+
+MODE_EXACT, MODE_FAST, MODE_DOUBLE, MODE_UNFUSED = 0, 1, 2, 3
+
+c_pd = ctypes.c_ssize_t  # ptrdiff_t
+
+AllocFct = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t)
+DeallocFct = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+ThreadFct = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_uint32)
+ThreadPoolFct = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ThreadFct, ctypes.POINTER(ctypes.c_void_p),
+                                 ctypes.c_uint32, ctypes.c_uint32)
+
+
+class Version(ctypes.Structure):
+    _fields_ = [("major", ctypes.c_uint32), ("minor", ctypes.c_uint32), ("patch", ctypes.c_uint32),
+                ("string", ctypes.c_char_p)]
+
+
+class ImgParams(ctypes.Structure):
+    _fields_ = [("topLeft", ctypes.c_void_p), ("step", c_pd), ("stride", c_pd)]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32),
+                ("imgA", ImgParams), ("imgB", ImgParams),
+                ("ssimMap", ctypes.c_void_p), ("ssimStep", c_pd), ("ssimStride", c_pd),
+                ("alloc", AllocFct), ("dealloc", DeallocFct)]
+
+
+class ThreadPool(ctypes.Structure):
+    _fields_ = [("dispatch", ThreadPoolFct), ("context", ctypes.c_void_p), ("threadCount", ctypes.c_uint32)]
+
+
+class SsimError(RuntimeError):
+    def __init__(self, fn, code):
+        self.errno = code
+        RuntimeError.__init__(self, "%s failed: errno %d (%s)" % (fn, code, errno.errorcode.get(code, "?")))
+
+
+# every symbol include/rmgr/*.h declares with C linkage (tests check the library exports them all)
+C_SYMBOLS = [
+    "rmgr_ssim_get_version", "rmgr_ssim_init_interleaved", "rmgr_ssim_init_planar", "rmgr_ssim_use_default_allocator",
+    "rmgr_ssim_compute_ssim", "rmgr_ssim_compute_ssim_openmp",
+    "rmgr_ssim_hip_get_device_count", "rmgr_ssim_hip_create", "rmgr_ssim_hip_destroy", "rmgr_ssim_hip_set_mode",
+    "rmgr_ssim_hip_get_mode", "rmgr_ssim_hip_set_tuning", "rmgr_ssim_hip_compute_ssim_host",
+    "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
+    "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
+    "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
+]
+# non-inline C++ entry points of the reference, Itanium-mangled
+CXX_SYMBOLS = [
+    "_ZN4rmgr4ssim12compute_ssimEPfRK17rmgr_ssim_Params_PK21rmgr_ssim_ThreadPool_",
+    "_ZN4rmgr4ssim12compute_ssimERKNS0_6ParamsE",
+    "_ZN4rmgr4ssim11select_implENS0_14ImplementationE",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the product library.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("%s not found: build it with `make lib` (hipcc --offload-arch=gfx950); "
+                          "ssim_amd has no CPU fallback" % p)
+    lib = ctypes.CDLL(p)
+    vp, i32, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32
+    PP = ctypes.POINTER(Params)
+    sig = {
+        "rmgr_ssim_get_version": [ctypes.POINTER(Version)],
+        "rmgr_ssim_init_interleaved": [ctypes.POINTER(ImgParams), vp, c_pd, u32, u32],
+        "rmgr_ssim_init_planar": [ctypes.POINTER(ImgParams), ctypes.POINTER(vp), ctypes.POINTER(c_pd), u32],
+        "rmgr_ssim_use_default_allocator": [PP],
+        "rmgr_ssim_compute_ssim": [ctypes.POINTER(ctypes.c_float), PP, ctypes.POINTER(ThreadPool)],
+        "rmgr_ssim_compute_ssim_openmp": [ctypes.POINTER(ctypes.c_float), PP],
+        "rmgr_ssim_hip_get_device_count": [ctypes.POINTER(i32)],
+        "rmgr_ssim_hip_create": [ctypes.POINTER(vp), i32, vp],
+        "rmgr_ssim_hip_destroy": [vp],
+        "rmgr_ssim_hip_set_mode": [vp, i32],
+        "rmgr_ssim_hip_get_mode": [vp, ctypes.POINTER(i32)],
+        "rmgr_ssim_hip_set_tuning": [vp, i32, i32],
+        "rmgr_ssim_hip_compute_ssim_host": [vp, ctypes.POINTER(ctypes.c_float), PP, ctypes.POINTER(ThreadPool)],
+        "rmgr_ssim_hip_compute_ssim_device": [vp, ctypes.POINTER(ctypes.c_float), PP],
+        "rmgr_ssim_hip_enqueue_batch": [vp, u32, PP, vp],
+        "rmgr_ssim_hip_finalize": [u32, ctypes.POINTER(ctypes.c_double), u32, u32, ctypes.POINTER(ctypes.c_float)],
+        "rmgr_ssim_hip_synchronize": [vp],
+        "rmgr_ssim_hip_malloc": [vp, ctypes.POINTER(vp), ctypes.c_size_t],
+        "rmgr_ssim_hip_free": [vp, vp],
+        "rmgr_ssim_hip_memcpy_h2d": [vp, vp, vp, ctypes.c_size_t],
+        "rmgr_ssim_hip_memcpy_d2h": [vp, vp, vp, ctypes.c_size_t],
+        "rmgr_ssim_hip_set_profiling": [vp, i32],
+        "rmgr_ssim_hip_get_profile": [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i32
+    lib.rmgr_ssim_hip_describe.argtypes = [vp]
+    lib.rmgr_ssim_hip_describe.restype = ctypes.c_char_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(name, rc):
+    if rc != 0:
+        raise SsimError(name, rc)
+
+
+def device_count():
+    n = ctypes.c_int32(0)
+    _check("rmgr_ssim_hip_get_device_count", load_library().rmgr_ssim_hip_get_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def get_version():
+    v = Version()
+    _check("rmgr_ssim_get_version", load_library().rmgr_ssim_get_version(ctypes.byref(v)))
+    return (v.major, v.minor, v.patch, v.string.decode())
+
+
+def make_params(width, height, a_ptr, a_step, a_stride, b_ptr, b_step, b_stride, map_ptr=None, map_step=1, map_stride=None):
+    p = Params()
+    p.width, p.height = width, height
+    p.imgA = ImgParams(a_ptr, a_step, a_stride)
+    p.imgB = ImgParams(b_ptr, b_step, b_stride)
+    p.ssimMap = map_ptr
+    p.ssimStep = map_step
+    p.ssimStride = width if map_stride is None else map_stride
+    return p
+
+
+def finalize(sums, width, height):
+    """float(sum / double(width*height)) per entry, computed by the library (src/ssim.cpp:1102)."""
+    sums = np.ascontiguousarray(sums, np.float64)
+    out = np.empty(sums.shape, np.float32)
+    _check("rmgr_ssim_hip_finalize", load_library().rmgr_ssim_hip_finalize(
+        sums.size, sums.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), width, height,
+        out.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+    return out
+
+
+def compute_ssim(a, b, want_map=False, openmp=False, allocator=False):
+    """The drop-in entry point rmgr_ssim_compute_ssim() on two host uint8 planes (H x W numpy)."""
+    lib = load_library()
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    h, w = a.shape
+    m = np.empty((h, w), np.float32) if want_map else None
+    p = make_params(w, h, a.ctypes.data, 1, a.strides[0], b.ctypes.data, 1, b.strides[0],
+                    m.ctypes.data if want_map else None, 1, w)
+    if allocator:
+        _check("rmgr_ssim_use_default_allocator", lib.rmgr_ssim_use_default_allocator(ctypes.byref(p)))
+    out = ctypes.c_float()
+    if openmp:
+        _check("rmgr_ssim_compute_ssim_openmp", lib.rmgr_ssim_compute_ssim_openmp(ctypes.byref(out), ctypes.byref(p)))
+    else:
+        _check("rmgr_ssim_compute_ssim", lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None))
+    return np.float32(out.value), m
+
+
+class DeviceBuffer(object):
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = ctypes.c_void_p()
+        _check("rmgr_ssim_hip_malloc", ctx.lib.rmgr_ssim_hip_malloc(ctx.handle, ctypes.byref(p), nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _check("rmgr_ssim_hip_memcpy_h2d", self.ctx.lib.rmgr_ssim_hip_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        _check("rmgr_ssim_hip_memcpy_d2h", self.ctx.lib.rmgr_ssim_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.rmgr_ssim_hip_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+
+class Context(object):
+    """rmgr_ssim_hip_Context: one engine bound to one device and one stream."""
+
+    def __init__(self, device=0, stream=None, mode=MODE_EXACT):
+        self.lib = load_library()
+        h = ctypes.c_void_p()
+        _check("rmgr_ssim_hip_create", self.lib.rmgr_ssim_hip_create(ctypes.byref(h), device, stream))
+        self.handle = h
+        self.set_mode(mode)
+
+    def close(self):
+        if self.handle:
+            self.lib.rmgr_ssim_hip_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def describe(self):
+        return self.lib.rmgr_ssim_hip_describe(self.handle).decode()
+
+    def set_mode(self, mode):
+        _check("rmgr_ssim_hip_set_mode", self.lib.rmgr_ssim_hip_set_mode(self.handle, mode))
+
+    def set_tuning(self, strip_rows=0, variant=0):
+        _check("rmgr_ssim_hip_set_tuning", self.lib.rmgr_ssim_hip_set_tuning(self.handle, strip_rows, variant))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, max(int(nbytes), 1))
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return self.alloc(arr.nbytes).upload(arr)
+
+    def synchronize(self):
+        _check("rmgr_ssim_hip_synchronize", self.lib.rmgr_ssim_hip_synchronize(self.handle))
+
+    def compute_host(self, params, want_global=True, thread_pool=None):
+        out = ctypes.c_float()
+        rc = self.lib.rmgr_ssim_hip_compute_ssim_host(self.handle, ctypes.byref(out) if want_global else None,
+                                                      ctypes.byref(params), thread_pool)
+        _check("rmgr_ssim_hip_compute_ssim_host", rc)
+        return np.float32(out.value)
+
+    def compute_device(self, params, want_global=True):
+        out = ctypes.c_float()
+        rc = self.lib.rmgr_ssim_hip_compute_ssim_device(self.handle, ctypes.byref(out) if want_global else None, ctypes.byref(params))
+        _check("rmgr_ssim_hip_compute_ssim_device", rc)
+        return np.float32(out.value)
+
+    def enqueue_batch(self, params_array, count, sums_dev_ptr):
+        _check("rmgr_ssim_hip_enqueue_batch", self.lib.rmgr_ssim_hip_enqueue_batch(self.handle, count, params_array, sums_dev_ptr))
+
+    def set_profiling(self, on):
+        _check("rmgr_ssim_hip_set_profiling", self.lib.rmgr_ssim_hip_set_profiling(self.handle, 1 if on else 0))
+
+    def get_profile(self):
+        n = ctypes.c_uint64()
+        ms = ctypes.c_double()
+        _check("rmgr_ssim_hip_get_profile", self.lib.rmgr_ssim_hip_get_profile(self.handle, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    # ---- convenience used by the tests: planes given as numpy arrays, staged explicitly ----
+    def ssim_planes(self, a, b, want_map=False):
+        """Upload two H x W uint8 planes, run the device path, return (ssim, map or None)."""
+        a = np.ascontiguousarray(a)
+        b = np.ascontiguousarray(b)
+        h, w = a.shape
+        da, db = self.upload(a), self.upload(b)
+        dm = self.alloc(4 * w * h) if want_map else None
+        try:
+            p = make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr if dm else None, 1, w)
+            v = self.compute_device(p)
+            m = dm.download(np.float32, (h, w)) if dm else None
+        finally:
+            da.free()
+            db.free()
+            if dm:
+                dm.free()
+        return v, m

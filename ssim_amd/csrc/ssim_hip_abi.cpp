@@ -1,0 +1,503 @@
+// ssim_hip_abi.cpp -- implementation of the C ABI declared in include/rmgr/ssim-hip.h.
+//
+// Host-side driver of the GPU path: what src/ssim.cpp:933-1106 (compute_ssim) is to the
+// reference's tile kernels, this file is to ssim_kernels.hip -- parameter validation with the
+// reference's error codes, staging, launch, final mean.  No CPU arithmetic fallback exists: when
+// no gfx950 device is usable every entry point fails loudly with ENODEV.
+#include <rmgr/ssim-hip.h>
+#include "ssim_kernels.h"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+using ssim_hip::PairDesc;
+
+struct rmgr_ssim_hip_Context_ {
+    int         device;
+    int         cu_count;
+    hipStream_t stream;
+    bool        owns_stream;
+    int         mode;
+    int         strip_rows;
+    int         variant;
+
+    // grow-only device scratch
+    double*   partials;     size_t partials_cap;   // doubles
+    double*   sums;         size_t sums_cap;       // doubles
+    PairDesc* descs;        size_t descs_cap;      // entries
+    uint8_t*  stage_a;      size_t stage_a_cap;    // bytes (host-pointer path)
+    uint8_t*  stage_b;      size_t stage_b_cap;
+    float*    stage_map;    size_t stage_map_cap;  // floats
+    // pinned host scratch
+    double*   h_sums;       size_t h_sums_cap;     // doubles
+    PairDesc* h_descs;      size_t h_descs_cap;
+    size_t    descs_live;   // entries of `descs` that mirror h_descs (0: nothing uploaded)
+
+    bool profiling;
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;   // recorded, not yet read
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > free_events;
+    uint64_t prof_launches;
+    double   prof_ms;
+
+    char describe[256];
+    std::mutex lock;
+};
+
+namespace {
+
+int map_hip_error(hipError_t e)
+{
+    switch (e) {
+    case hipSuccess:                return 0;
+    case hipErrorOutOfMemory:       return ENOMEM;
+    case hipErrorNoDevice:
+    case hipErrorInvalidDevice:
+    case hipErrorInsufficientDriver:
+    case hipErrorNoBinaryForGpu:
+    case hipErrorInvalidDeviceFunction:
+        return ENODEV;
+    case hipErrorInvalidValue:      return EINVAL;
+    default:                        return ECHILD;   // "an error occurred in a worker" (src/ssim.cpp:1096-1097)
+    }
+}
+
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return map_hip_error(e_); } } while (0)
+
+template <typename T>
+int grow_device(T*& ptr, size_t& cap, size_t need)
+{
+    if (need <= cap) return 0;
+    if (ptr) { HIP_TRY(hipFree(ptr)); ptr = NULL; cap = 0; }
+    size_t n = need + need / 4 + 64;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+    cap = n;
+    return 0;
+}
+
+template <typename T>
+int grow_pinned(T*& ptr, size_t& cap, size_t need)
+{
+    if (need <= cap) return 0;
+    if (ptr) { HIP_TRY(hipHostFree(ptr)); ptr = NULL; cap = 0; }
+    size_t n = need + need / 4 + 64;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T), hipHostMallocDefault));
+    cap = n;
+    return 0;
+}
+
+// The reference's parameter checks, in its order (src/ssim.cpp:962-978).
+int validate(const float* ssim, const rmgr_ssim_Params* p, const rmgr_ssim_ThreadPool* tp)
+{
+    if (p == NULL) return EINVAL;                                    // src/ssim.cpp:1147-1151
+    if (ssim == NULL && p->ssimMap == NULL) return EINVAL;
+    if (p->imgA.topLeft == NULL || p->imgB.topLeft == NULL) return EINVAL;
+    if (tp != NULL && tp->dispatch != NULL && tp->threadCount == 0u) return EINVAL;
+    return 0;
+}
+
+// Byte extent [lo, hi] (inclusive, relative to topLeft) touched by a width x height image.
+void extent(const rmgr_ssim_ImgParams& im, uint32_t w, uint32_t h, int64_t& lo, int64_t& hi)
+{
+    const int64_t dx = (int64_t)(w - 1) * (int64_t)im.step, dy = (int64_t)(h - 1) * (int64_t)im.stride;
+    lo = (dx < 0 ? dx : 0) + (dy < 0 ? dy : 0);
+    hi = (dx > 0 ? dx : 0) + (dy > 0 ? dy : 0);
+}
+
+int record_begin(rmgr_ssim_hip_Context* c, hipEvent_t& b, hipEvent_t& e)
+{
+    b = e = NULL;
+    if (!c->profiling) return 0;
+    if (!c->free_events.empty()) {
+        b = c->free_events.back().first; e = c->free_events.back().second;
+        c->free_events.pop_back();
+    } else {
+        HIP_TRY(hipEventCreate(&b));
+        HIP_TRY(hipEventCreate(&e));
+    }
+    c->pending.push_back(std::make_pair(b, e));
+    return 0;
+}
+
+int drain_profile(rmgr_ssim_hip_Context* c)
+{
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->pending[i].second));
+        HIP_TRY(hipEventElapsedTime(&ms, c->pending[i].first, c->pending[i].second));
+        c->prof_ms += ms;
+        c->prof_launches += 1;
+        c->free_events.push_back(c->pending[i]);
+    }
+    c->pending.clear();
+    return 0;
+}
+
+// Enqueue kernel + reduction for `count` pairs whose descriptors are in `descs` (host).
+int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev)
+{
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count);
+    int rc = grow_device(c->partials, c->partials_cap, (size_t)count * geo.partials_per_image() + 1);
+    if (rc) return rc;
+    PairDesc single = descs[0];
+    const PairDesc* descs_dev = NULL;
+    if (count > 1) {
+        // Re-enqueueing the same batch (the steady state of a serving loop) reuses the uploaded
+        // descriptor table; a different batch waits for the stream before the pinned mirror and
+        // the device table are overwritten.
+        if (!(c->descs_live == count && memcmp(c->h_descs, descs, sizeof(PairDesc) * count) == 0)) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->descs_live = 0;
+            if ((rc = grow_device(c->descs, c->descs_cap, count))) return rc;
+            if ((rc = grow_pinned(c->h_descs, c->h_descs_cap, count))) return rc;
+            memcpy(c->h_descs, descs, sizeof(PairDesc) * count);
+            HIP_TRY(hipMemcpyAsync(c->descs, c->h_descs, sizeof(PairDesc) * count, hipMemcpyHostToDevice, c->stream));
+            c->descs_live = count;
+        }
+        descs_dev = c->descs;
+        if (any_map && !single.map) single.map = reinterpret_cast<float*>(1);  // only its non-NULLness is used
+    }
+    hipEvent_t eb, ee;
+    if ((rc = record_begin(c, eb, ee))) return rc;
+    HIP_TRY(ssim_hip::launch(geo, c->mode, c->variant, descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
+    return 0;
+}
+
+PairDesc make_desc(const rmgr_ssim_Params& p)
+{
+    PairDesc d;
+    d.a = p.imgA.topLeft; d.a_step = p.imgA.step; d.a_stride = p.imgA.stride;
+    d.b = p.imgB.topLeft; d.b_step = p.imgB.step; d.b_stride = p.imgB.stride;
+    d.map = p.ssimMap;
+    d.map_step = p.ssimMap ? p.ssimStep : 0;      // src/ssim.cpp:980-987
+    d.map_stride = p.ssimMap ? p.ssimStride : 0;
+    return d;
+}
+
+float mean_of(double sum, uint32_t width, uint32_t height)
+{
+    return float(sum / double(uint32_t(width * height)));   // src/ssim.cpp:1102 (32-bit product kept)
+}
+
+rmgr_ssim_hip_Context* g_default = NULL;
+int                    g_default_err = 0;
+std::once_flag         g_default_once;
+
+rmgr_ssim_hip_Context* default_context(int* err)
+{
+    std::call_once(g_default_once, []() {
+        int dev = 0;
+        if (const char* s = getenv("RMGR_SSIM_HIP_DEVICE")) dev = atoi(s);
+        g_default_err = rmgr_ssim_hip_create(&g_default, dev, NULL);
+        if (g_default && g_default_err == 0) {
+            if (const char* m = getenv("RMGR_SSIM_HIP_MODE")) g_default->mode = atoi(m);
+#if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
+            else g_default->mode = RMGR_SSIM_HIP_MODE_DOUBLE;
+#endif
+        }
+    });
+    *err = g_default_err;
+    return g_default;
+}
+
+} // namespace
+
+extern "C" {
+
+rmgr_int32_t rmgr_ssim_hip_get_device_count(rmgr_int32_t* count) RMGR_NOEXCEPT
+{
+    if (!count) return EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t device, void* stream) RMGR_NOEXCEPT
+{
+    if (!out) return EINVAL;
+    *out = NULL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ENODEV; }
+    if (device < 0 || device >= n) return EINVAL;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    rmgr_ssim_hip_Context* c = new (std::nothrow) rmgr_ssim_hip_Context_();
+    if (!c) return ENOMEM;
+    c->device = device;
+    c->cu_count = prop.multiProcessorCount;
+    c->stream = static_cast<hipStream_t>(stream);
+    c->owns_stream = false;
+    c->mode = RMGR_SSIM_HIP_MODE_EXACT;
+    c->strip_rows = 0;
+    c->variant = 0;
+    c->partials = NULL; c->partials_cap = 0;
+    c->sums = NULL; c->sums_cap = 0;
+    c->descs = NULL; c->descs_cap = 0;
+    c->stage_a = NULL; c->stage_a_cap = 0;
+    c->stage_b = NULL; c->stage_b_cap = 0;
+    c->stage_map = NULL; c->stage_map_cap = 0;
+    c->h_sums = NULL; c->h_sums_cap = 0;
+    c->h_descs = NULL; c->h_descs_cap = 0;
+    c->descs_live = 0;
+    c->profiling = false;
+    c->prof_launches = 0;
+    c->prof_ms = 0.0;
+    if (!stream) {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return map_hip_error(e); }
+        c->owns_stream = true;
+    }
+    snprintf(c->describe, sizeof(c->describe), "%s %s, %d CUs, %.0f MHz, %.1f GiB; rmgr-ssim hip backend (code object gfx950)",
+             prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0);
+    *out = c;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
+    for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->sums) (void)hipFree(c->sums);
+    if (c->descs) (void)hipFree(c->descs);
+    if (c->stage_a) (void)hipFree(c->stage_a);
+    if (c->stage_b) (void)hipFree(c->stage_b);
+    if (c->stage_map) (void)hipFree(c->stage_map);
+    if (c->h_sums) (void)hipHostFree(c->h_sums);
+    if (c->h_descs) (void)hipHostFree(c->h_descs);
+    if (c->owns_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode) RMGR_NOEXCEPT
+{
+    if (!c || mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_UNFUSED) return EINVAL;
+    c->mode = mode;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* c, rmgr_int32_t* mode) RMGR_NOEXCEPT
+{
+    if (!c || !mode) return EINVAL;
+    *mode = c->mode;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT
+{
+    if (!c || stripRows < 0 || variant < 0) return EINVAL;
+    c->strip_rows = stripRows;
+    c->variant = variant;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t count, const rmgr_ssim_Params* params, double* sumsDevice) RMGR_NOEXCEPT
+{
+    if (!c || (count && (!params || !sumsDevice))) return EINVAL;
+    if (count == 0) return 0;
+    bool any_map = false;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (params[i].imgA.topLeft == NULL || params[i].imgB.topLeft == NULL) return EINVAL;
+        if (params[i].width != params[0].width || params[i].height != params[0].height) return EINVAL;
+        any_map = any_map || params[i].ssimMap != NULL;
+    }
+    for (uint32_t i = 0; i < count; ++i)
+        if (any_map && params[i].ssimMap == NULL) return EINVAL;   // all or none
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<PairDesc> descs(count);
+    for (uint32_t i = 0; i < count; ++i) descs[i] = make_desc(params[i]);
+    return enqueue(c, params[0].width, params[0].height, count, descs.data(), any_map, sumsDevice);
+}
+
+rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT
+{
+    if (count && (!sums || !ssim)) return EINVAL;
+    for (uint32_t i = 0; i < count; ++i) ssim[i] = mean_of(sums[i], width, height);
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* c, float* ssim, const rmgr_ssim_Params* params) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    int rc = validate(ssim, params, NULL);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
+    if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
+    const PairDesc d = make_desc(*params);
+    if ((rc = enqueue(c, params->width, params->height, 1, &d, d.map != NULL, c->sums))) return rc;
+    if (ssim) {
+        HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        *ssim = mean_of(c->h_sums[0], params->width, params->height);
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ssim, const rmgr_ssim_Params* params,
+                                             const rmgr_ssim_ThreadPool* threadPool) RMGR_NOEXCEPT
+{
+    int rc = validate(ssim, params, threadPool);
+    if (rc) return rc;
+    std::unique_lock<std::mutex> guard;
+    if (!c) {
+        c = default_context(&rc);
+        if (rc) return rc;
+        if (!c) return ENODEV;
+        guard = std::unique_lock<std::mutex>(c->lock);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t W = params->width, H = params->height;
+
+    // The reference allocates its tile scratch through params->alloc exactly once and fails with
+    // ENOMEM when that returns NULL (src/ssim.cpp:1048-1052).  Here the user allocator provides the
+    // host-side bounce buffer of the map (and keeps the ENOMEM contract observable).
+    const bool scatter_map = params->ssimMap != NULL && W && H && !(params->ssimStep == 1 && params->ssimStride >= (ptrdiff_t)W);
+    void* user_mem = NULL;
+    if (params->alloc != NULL) {
+        const size_t bytes = scatter_map ? sizeof(float) * (size_t)W * H : 64;
+        user_mem = params->alloc(bytes, 64);
+        if (user_mem == NULL) return ENOMEM;
+    }
+    struct Release {
+        const rmgr_ssim_Params* p; void* m; std::vector<float> own;
+        ~Release() { if (m && p->dealloc) p->dealloc(m); }
+    } rel = {params, user_mem, std::vector<float>()};
+
+    rmgr_ssim_Params dev = *params;
+    if (W && H) {
+        // Stage the byte range each image occupies; step/stride semantics carry over unchanged.
+        int64_t loA, hiA, loB, hiB;
+        extent(params->imgA, W, H, loA, hiA);
+        extent(params->imgB, W, H, loB, hiB);
+        const size_t nA = (size_t)(hiA - loA + 1), nB = (size_t)(hiB - loB + 1);
+        if ((rc = grow_device(c->stage_a, c->stage_a_cap, nA))) return rc;
+        if ((rc = grow_device(c->stage_b, c->stage_b_cap, nB))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->stage_a, params->imgA.topLeft + loA, nA, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->stage_b, params->imgB.topLeft + loB, nB, hipMemcpyHostToDevice, c->stream));
+        dev.imgA.topLeft = c->stage_a - loA;
+        dev.imgB.topLeft = c->stage_b - loB;
+        if (params->ssimMap) {
+            if ((rc = grow_device(c->stage_map, c->stage_map_cap, (size_t)W * H))) return rc;
+            dev.ssimMap = c->stage_map;      // dense W x H on the device
+            dev.ssimStep = 1;
+            dev.ssimStride = W;
+        }
+    } else {
+        dev.ssimMap = NULL;
+    }
+
+    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
+    if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
+    const PairDesc d = make_desc(dev);
+    if ((rc = enqueue(c, W, H, 1, &d, d.map != NULL, c->sums))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+
+    if (params->ssimMap && W && H) {
+        if (!scatter_map) {
+            HIP_TRY(hipMemcpy2DAsync(params->ssimMap, sizeof(float) * (size_t)params->ssimStride, c->stage_map, sizeof(float) * W,
+                                     sizeof(float) * W, H, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        } else {
+            float* bounce = static_cast<float*>(user_mem);
+            if (!bounce) {
+                try { rel.own.resize((size_t)W * H); } catch (...) { return ENOMEM; }
+                bounce = rel.own.data();
+            }
+            HIP_TRY(hipMemcpyAsync(bounce, c->stage_map, sizeof(float) * (size_t)W * H, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (uint32_t y = 0; y < H; ++y) {
+                float* row = params->ssimMap + (ptrdiff_t)y * params->ssimStride;
+                const float* src = bounce + (size_t)y * W;
+                for (uint32_t x = 0; x < W; ++x)
+                    row[(ptrdiff_t)x * params->ssimStep] = src[x];
+            }
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (ssim)
+        *ssim = mean_of(c->h_sums[0], W, H);
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_malloc(rmgr_ssim_hip_Context* c, void** p, size_t size) RMGR_NOEXCEPT
+{
+    if (!c || !p) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(p, size ? size : 1));
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_free(rmgr_ssim_hip_Context* c, void* p) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_memcpy_h2d(rmgr_ssim_hip_Context* c, void* dst, const void* src, size_t size) RMGR_NOEXCEPT
+{
+    if (!c || (size && (!dst || !src))) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* c, void* dst, const void* src, size_t size) RMGR_NOEXCEPT
+{
+    if (!c || (size && (!dst || !src))) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* c, rmgr_int32_t enabled) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    c->profiling = enabled != 0;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* c, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = drain_profile(c);
+    if (rc) return rc;
+    if (launches) *launches = c->prof_launches;
+    if (kernelMs) *kernelMs = c->prof_ms;
+    c->prof_launches = 0;
+    c->prof_ms = 0.0;
+    return 0;
+}
+
+const char* rmgr_ssim_hip_describe(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    return c ? c->describe : "rmgr-ssim hip backend (no context)";
+}
+
+} // extern "C"

@@ -1,0 +1,43 @@
+// ssim_kernels.h -- internal interface between the C ABI (ssim_hip_abi.cpp) and the gfx950
+// kernels (ssim_kernels.hip).  Not installed; nothing here is visible through include/rmgr/.
+#ifndef SSIM_AMD_KERNELS_H
+#define SSIM_AMD_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ssim_hip {
+
+// One image pair as the kernels address it: pixel (x,y) of A is a[x*a_step + y*a_stride]
+// (bytes, signed), map element (x,y) is map[x*map_step + y*map_stride] (floats, signed).
+// Mirrors rmgr_ssim_Params (include/rmgr/ssim.h) with device pointers.
+struct PairDesc {
+    const uint8_t* a;  int64_t a_step, a_stride;
+    const uint8_t* b;  int64_t b_step, b_stride;
+    float*         map; int64_t map_step, map_stride;
+};
+
+enum Mode { MODE_EXACT = 0, MODE_FAST = 1, MODE_DOUBLE = 2, MODE_UNFUSED = 3 };
+
+struct Geometry {
+    uint32_t width, height, count;
+    uint32_t strip_w;      // output columns per wavefront strip (64 or 128, by kernel)
+    uint32_t strip_rows;   // output rows per wavefront strip
+    uint32_t strips_x, strips_y;
+    uint32_t partials_per_image() const { return strips_x * strips_y; }
+};
+
+// Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count);
+
+// Enqueues the SSIM kernel + the per-image reduction on `stream`.
+//   descs_dev   count descriptors in device memory, or NULL when count == 1 and `single` is used
+//   partials    device scratch, >= count * geo.partials_per_image() doubles
+//   sums        device, count doubles: per-image fp64 sum of the SSIM values
+// ev_begin/ev_end (optional) are recorded around the main kernel only.
+hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* descs_dev, const PairDesc& single,
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end);
+
+} // namespace ssim_hip
+
+#endif

@@ -1,0 +1,515 @@
+// ssim_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the SSIM hot path.
+//
+// Replaces, in one fused launch, the reference's per-tile chain
+//   retrieve_tile x2 -> multiply x3 -> gaussian_blur x5 -> sum_tile     (src/ssim.cpp:747-783)
+// and, in a second tiny launch, the final reduce (src/ssim.cpp:1090-1103, minus the division,
+// which the host does in fp64 exactly as the reference: include/rmgr/ssim-hip.h finalize).
+//
+// Design (DESIGN.md has the long form):
+//  * Work unit = one 64-lane wavefront = one workgroup = one vertical STRIP of the image:
+//    64*C adjacent output columns (C = columns per lane) x strip_rows output rows.  No
+//    inter-wave communication, hence no real barriers; thousands of strips fill 256 CUs.
+//  * The strip walks DOWN its rows.  Per source row the wave (a) loads the row's uint8 pixels
+//    of A and B (edge-clamped, any step/stride) one row ahead into registers, (b) converts them
+//    and writes the five statistic planes a, b, a^2, b^2, ab of that row into a 2-slot LDS ring
+//    (plane pairs (a,b) and (a^2,b^2) interleaved as float2 so that packed-fp32 VALU ops work
+//    on naturally aligned register pairs), (c) every lane reads the 11(+1)-pixel window of its
+//    columns back with wide ds_reads and runs the blur as a row SCATTER into an 11-deep register
+//    ring of accumulators -- the reference's own formulation (src/ssim_fma.cpp:246-257), so that
+//    MODE_EXACT reproduces its rounding order bit for bit -- and (d) the ring's oldest entry is
+//    a finished output row: SSIM formula, fp64 accumulation, optional map store.
+//  * Intermediates never touch HBM: algorithmic traffic is 2 B/pixel (+4 B/pixel with a map).
+//  * The kernel is fp32-VALU bound (~150 packed instructions per pixel in MODE_EXACT), not HBM
+//    bound; see DESIGN.md for the roofline arithmetic.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off   (fusion only where fma is written;
+// float division stays IEEE correctly rounded: no -ffast-math anywhere).
+#include "ssim_kernels.h"
+#include <cmath>
+#include <type_traits>
+
+namespace ssim_hip {
+namespace {
+
+typedef float  f2 __attribute__((ext_vector_type(2)));
+typedef float  f4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// Pointers that arrive inside structs lose their address space and would compile to flat_*
+// accesses (which also tick the LDS counter).  Everything the kernel touches in memory is global.
+typedef const uint8_t __attribute__((address_space(1)))*  gptr_u8;
+typedef float __attribute__((address_space(1)))*          gptr_f32;
+typedef double __attribute__((address_space(1)))*         gptr_f64;
+typedef const PairDesc __attribute__((address_space(1)))* gptr_desc;
+
+// ---------------------------------------------------------------------------------------------
+// The 21 unique taps K(i,j), i<=j, of the reference's SIMD paths (src/ssim_fma.cpp:169-174):
+// the float-computed 11x11 sigma=1.5 window.  Pure constexpr functions of literals so that
+// every use folds to an inline constant / SGPR.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr float ktab(int n)
+{
+    return n ==  0 ? 7.07622393965721130e-02f :
+           n ==  1 ? 5.66619709134101868e-02f : n ==  2 ? 4.53713610768318176e-02f :
+           n ==  3 ? 2.90912277996540070e-02f : n ==  4 ? 2.32944320887327194e-02f : n ==  5 ? 1.19597595185041428e-02f :
+           n ==  6 ? 9.57662798464298248e-03f : n ==  7 ? 7.66836293041706085e-03f : n ==  8 ? 3.93706932663917542e-03f :
+           n ==  9 ? 1.29605561960488558e-03f :
+           n == 10 ? 2.02135881409049034e-03f : n == 11 ? 1.61857774946838617e-03f : n == 12 ? 8.31005279906094074e-04f :
+           n == 13 ? 2.73561221547424793e-04f : n == 14 ? 5.77411265112459660e-05f :
+           n == 15 ? 2.73561221547424793e-04f : n == 16 ? 2.19050692976452410e-04f : n == 17 ? 1.12464345875196159e-04f :
+           n == 18 ? 3.70224843209143728e-05f : n == 19 ? 7.81441485742107034e-06f : 1.05756600987660931e-06f;
+}
+__host__ __device__ constexpr float kc(int i, int j) { return ktab(i <= j ? j * (j + 1) / 2 + i : i * (i + 1) / 2 + j); }
+
+// ---------------------------------------------------------------------------------------------
+// Small generic helpers over the stream value types: f2 (two planes or two columns packed ->
+// v_pk_*_f32), float, d2, double.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float  fma_(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ f2     fma_(f2 a, f2 b, f2 c)             { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ d2     fma_(d2 a, d2 b, d2 c)             { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename V> struct VT;
+template <> struct VT<float>  { typedef float  S; static __device__ __forceinline__ float  splat(float k)  { return k; } };
+template <> struct VT<f2>     { typedef float  S; static __device__ __forceinline__ f2     splat(float k)  { f2 v = {k, k}; return v; } };
+template <> struct VT<double> { typedef double S; static __device__ __forceinline__ double splat(double k) { return k; } };
+template <> struct VT<d2>     { typedef double S; static __device__ __forceinline__ d2     splat(double k) { d2 v = {k, k}; return v; } };
+
+__device__ __forceinline__ double to_f64(float v) { return (double)v; }
+__device__ __forceinline__ d2     to_f64(f2 v)    { d2 r = {(double)v.x, (double)v.y}; return r; }
+
+// One multiply-accumulate step of the blur: fused (FMA path, src/ssim_fma.cpp:210-243) or with
+// separately rounded product and sum (MUL_ADD of the generic/SSE/AVX paths, src/ssim.cpp:353).
+template <bool FUSED, typename V>
+__device__ __forceinline__ V mad(V a, V b, V c)
+{
+    if constexpr (FUSED) return fma_(a, b, c);
+    else                 return c + a * b;
+}
+
+// sum_J = s0*K(0,J) then five multiply-adds in i order (src/ssim_fma.cpp:203-243).
+template <int J, bool FUSED, typename V>
+__device__ __forceinline__ V row_sum(V s0, V s1, V s2, V s3, V s4, V s5)
+{
+    V t = s0 * VT<V>::splat(kc(0, J));
+    t = mad<FUSED>(s1, VT<V>::splat(kc(1, J)), t);
+    t = mad<FUSED>(s2, VT<V>::splat(kc(2, J)), t);
+    t = mad<FUSED>(s3, VT<V>::splat(kc(3, J)), t);
+    t = mad<FUSED>(s4, VT<V>::splat(kc(4, J)), t);
+    t = mad<FUSED>(s5, VT<V>::splat(kc(5, J)), t);
+    return t;
+}
+
+// Reference-order blur of one source row into the 11-deep accumulator ring of one stream.
+// acc[k] is the partial result of output row (r-5+k) while source row r is processed; the
+// scatter "rows r-5..r+5 += sum5,sum4,..,sum0,..,sum5" (src/ssim_fma.cpp:246-257) becomes a
+// shift of the ring (3-address adds: the shift is free).  Every output row therefore receives
+// its 11 addends in source-row order, first one added to zero, exactly like the reference.
+template <bool FUSED, typename V>
+__device__ __forceinline__ void blur_exact(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5)
+{
+    const V S0 = row_sum<0, FUSED>(s0, s1, s2, s3, s4, s5);
+    const V S1 = row_sum<1, FUSED>(s0, s1, s2, s3, s4, s5);
+    const V S2 = row_sum<2, FUSED>(s0, s1, s2, s3, s4, s5);
+    const V S3 = row_sum<3, FUSED>(s0, s1, s2, s3, s4, s5);
+    const V S4 = row_sum<4, FUSED>(s0, s1, s2, s3, s4, s5);
+    const V S5 = row_sum<5, FUSED>(s0, s1, s2, s3, s4, s5);
+    acc[0] = S5 + acc[1];
+    acc[1] = S4 + acc[2];
+    acc[2] = S3 + acc[3];
+    acc[3] = S2 + acc[4];
+    acc[4] = S1 + acc[5];
+    acc[5] = S0 + acc[6];
+    acc[6] = S1 + acc[7];
+    acc[7] = S2 + acc[8];
+    acc[8] = S3 + acc[9];
+    acc[9] = S4 + acc[10];
+    acc[10] = S5;
+}
+
+// Separable blur (MODE_FAST fp32 / MODE_DOUBLE fp64): 1-D pass along the row on the folded
+// sums, then the vertical pass as the same ring scatter.  g[] = centre..edge taps of the true
+// 1-D Gaussian (g(x)g(y) equals the 2-D kernel of tests/ssim_naive.h to 7e-18).
+template <typename V, typename G>
+__device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5, const G (&g)[6])
+{
+    V h = s0 * VT<V>::splat(g[0]);
+    h = fma_(s1, VT<V>::splat(g[1]), h);
+    h = fma_(s2, VT<V>::splat(g[2]), h);
+    h = fma_(s3, VT<V>::splat(g[3]), h);
+    h = fma_(s4, VT<V>::splat(g[4]), h);
+    h = fma_(s5, VT<V>::splat(g[5]), h);
+    acc[0] = fma_(h, VT<V>::splat(g[5]), acc[1]);
+    acc[1] = fma_(h, VT<V>::splat(g[4]), acc[2]);
+    acc[2] = fma_(h, VT<V>::splat(g[3]), acc[3]);
+    acc[3] = fma_(h, VT<V>::splat(g[2]), acc[4]);
+    acc[4] = fma_(h, VT<V>::splat(g[1]), acc[5]);
+    acc[5] = fma_(h, VT<V>::splat(g[0]), acc[6]);
+    acc[6] = fma_(h, VT<V>::splat(g[1]), acc[7]);
+    acc[7] = fma_(h, VT<V>::splat(g[2]), acc[8]);
+    acc[8] = fma_(h, VT<V>::splat(g[3]), acc[9]);
+    acc[9] = fma_(h, VT<V>::splat(g[4]), acc[10]);
+    acc[10] = h * VT<V>::splat(g[5]);
+}
+
+// Per-pixel SSIM, unfused fp32 exactly as src/ssim.cpp:681-693 / src/ssim_avx.cpp:342-352.
+// 2*x + c is written as fma(2,x,c): 2*x is exact, so the single rounding is the same one.
+__device__ __forceinline__ float ssim_px(float muA, float muB, float eAA, float eBB, float eAB, float c1, float c2)
+{
+    const float muA2 = muA * muA, muB2 = muB * muB, muAB = muA * muB;
+    const float sA2 = eAA - muA2, sB2 = eBB - muB2, sAB = eAB - muAB;
+    const float num = __builtin_fmaf(2.0f, muAB, c1) * __builtin_fmaf(2.0f, sAB, c2);
+    const float den = ((muA2 + muB2) + c1) * ((sA2 + sB2) + c2);
+    return num / den;
+}
+__device__ __forceinline__ double ssim_px(double muA, double muB, double eAA, double eBB, double eAB, double c1, double c2)
+{
+    const double muA2 = muA * muA, muB2 = muB * muB, muAB = muA * muB;
+    const double sA2 = eAA - muA2, sB2 = eBB - muB2, sAB = eAB - muAB;
+    const double num = (2 * muAB + c1) * (2 * sAB + c2);
+    const double den = ((muA2 + muB2) + c1) * ((sA2 + sB2) + c2);
+    return num / den;
+}
+
+struct KArgs {
+    PairDesc        single;       // used when descs == nullptr
+    const PairDesc* descs;
+    uint32_t        width, height, strip_rows, strips_x, strips_y;
+    double*         partials;     // [image][strip_y][strip_x]
+    float           c1, c2;
+    float           gf[6];        // separable taps, fp32
+    double          c1d, c2d;
+    double          gd[6];        // separable taps, fp64
+};
+
+// LDS row slot: the five statistic planes of one source row, PAD pixels of halo each side
+// (5 needed; 8 keeps every wide read naturally aligned).
+template <int C>
+struct RowSlot {
+    static constexpr int STRIP_W = 64 * C;
+    static constexpr int PAD = 8;
+    static constexpr int ROW_PX = STRIP_W + 2 * PAD;
+    f2    ab[ROW_PX];   // (a, b)
+    f2    q[ROW_PX];    // (a*a, b*b)
+    float x[ROW_PX];    // a*b
+};
+
+// ---------------------------------------------------------------------------------------------
+// The strip kernel.  MODE: arithmetic; C: columns per lane; MAP: write the per-pixel map.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int C, bool MAP>
+__global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
+{
+    typedef RowSlot<C> Slot;
+    constexpr int STRIP_W = Slot::STRIP_W, PAD = Slot::PAD, ROW_PX = Slot::ROW_PX;
+    constexpr int NLOAD = (ROW_PX + 63) / 64;  // pixels each lane stages per row (2 or 3)
+    constexpr bool DBL = (MODE == MODE_DOUBLE);
+    constexpr bool FUSED = (MODE != MODE_UNFUSED);
+    static_assert(!DBL || C == 1, "fp64 mode runs one column per lane");
+    typedef typename std::conditional<DBL, d2, f2>::type PV;                                     // plane-pair streams
+    typedef typename std::conditional<DBL, double, typename std::conditional<C == 2, f2, float>::type>::type XV;  // ab stream
+
+    __shared__ __attribute__((aligned(16))) Slot ring[2];
+
+    const int lane = threadIdx.x;
+    PairDesc pd = args.single;
+    if (args.descs) {
+        const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
+        pd.a = gd->a; pd.a_step = gd->a_step; pd.a_stride = gd->a_stride;
+        pd.b = gd->b; pd.b_step = gd->b_step; pd.b_stride = gd->b_stride;
+        pd.map = gd->map; pd.map_step = gd->map_step; pd.map_stride = gd->map_stride;
+    }
+    const int64_t W = args.width, H = args.height;
+    const int64_t x0 = (int64_t)blockIdx.x * STRIP_W;
+    const int64_t y0 = (int64_t)blockIdx.y * args.strip_rows;
+    const int64_t y_end = (y0 + args.strip_rows < H) ? y0 + args.strip_rows : H;
+
+    // Per-lane staging columns: pixel p of the slot is image column clamp(x0 - PAD + p)
+    // (edge replication of the IMAGE, src/ssim.cpp:529-554).
+    int     sp[NLOAD];
+    int64_t offA[NLOAD], offB[NLOAD];
+#pragma unroll
+    for (int t = 0; t < NLOAD; ++t) {
+        int p = lane + 64 * t;
+        p = p < ROW_PX ? p : ROW_PX - 1;
+        int64_t xg = x0 - PAD + p;
+        xg = xg < 0 ? 0 : (xg > W - 1 ? W - 1 : xg);
+        sp[t] = p;
+        offA[t] = xg * pd.a_step;
+        offB[t] = xg * pd.b_step;
+    }
+
+    uint8_t va[NLOAD], vb[NLOAD];
+    auto fetch = [&](int64_t r) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
+        const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+        const gptr_u8 ra = (gptr_u8)pd.a + ry * pd.a_stride;
+        const gptr_u8 rb = (gptr_u8)pd.b + ry * pd.b_stride;
+#pragma unroll
+        for (int t = 0; t < NLOAD; ++t) {
+            va[t] = ra[offA[t]];
+            vb[t] = rb[offB[t]];
+        }
+    };
+    auto stage = [&](Slot& s) {    // registers -> the five planes of one LDS slot
+#pragma unroll
+        for (int t = 0; t < NLOAD; ++t) {
+            const float a = (float)va[t], b = (float)vb[t];   // retrieve_tile: uint8 -> Float
+            const f2 ab = {a, b};
+            s.ab[sp[t]] = ab;
+            s.q[sp[t]] = ab * ab;                              // multiply: a*a, b*b (exact)
+            s.x[sp[t]] = a * b;                                //           a*b
+        }
+    };
+
+    // Accumulator rings (zero == the memset of src/ssim_fma.cpp:187).
+    PV accAB[C][11], accQ[C][11];
+    XV accX[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            accAB[c][k] = VT<PV>::splat(0);
+            accQ[c][k] = VT<PV>::splat(0);
+        }
+        accX[k] = VT<XV>::splat(0);
+    }
+
+    double colsum[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) colsum[c] = 0.0;
+
+    const int64_t r_begin = y0 - 5, r_end = y_end + 5;
+    fetch(r_begin);
+    stage(ring[0]);
+    fetch(r_begin + 1);
+    int cur = 0;
+
+#pragma unroll 1
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        // Software pipeline: row r+1 goes to the other slot, row r+2 is requested from memory,
+        // then row r is consumed.  One wave == one workgroup: the barrier only orders LDS.
+        stage(ring[cur ^ 1]);
+        fetch(r + 2);
+        __syncthreads();
+        const Slot& s = ring[cur];
+
+        // ---- window reads: this lane's C columns sit at slot pixels C*lane+PAD .. +C-1 ----
+        constexpr int WN = (C == 2) ? 14 : 11;            // pixels read per plane
+        constexpr int CTR = (C == 2) ? 6 : 5;             // index of column 0's centre
+        f2 wab[WN], wq[WN];
+        float wx[WN];
+        if constexpr (C == 2) {
+            const int base = 2 * lane + PAD - 6;           // even -> 16-byte aligned f4 reads
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const f4 v = *reinterpret_cast<const f4*>(&s.ab[base + 2 * t]);
+                const f4 u = *reinterpret_cast<const f4*>(&s.q[base + 2 * t]);
+                const f2 z = *reinterpret_cast<const f2*>(&s.x[base + 2 * t]);
+                wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
+                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+                wx[2 * t] = z.x;   wx[2 * t + 1] = z.y;
+            }
+        } else {
+            const int base = lane + PAD - 5;
+#pragma unroll
+            for (int t = 0; t < 11; ++t) {
+                wab[t] = s.ab[base + t];
+                wq[t] = s.q[base + t];
+                wx[t] = s.x[base + t];
+            }
+        }
+
+        // ---- blur: fold s[x+i]+s[x-i] (src/ssim_fma.cpp:196-201), then the row scatter ----
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int m = CTR + c;
+            const f2 a1 = wab[m + 1] + wab[m - 1], a2 = wab[m + 2] + wab[m - 2], a3 = wab[m + 3] + wab[m - 3],
+                     a4 = wab[m + 4] + wab[m - 4], a5 = wab[m + 5] + wab[m - 5];
+            const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
+                     q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
+            if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
+                blur_exact<FUSED>(accAB[c], wab[m], a1, a2, a3, a4, a5);
+                blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
+            } else if constexpr (MODE == MODE_FAST) {
+                blur_separable(accAB[c], wab[m], a1, a2, a3, a4, a5, args.gf);
+                blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
+            } else {
+                blur_separable(accAB[c], to_f64(wab[m]), to_f64(a1), to_f64(a2), to_f64(a3), to_f64(a4), to_f64(a5), args.gd);
+                blur_separable(accQ[c], to_f64(wq[m]), to_f64(q1), to_f64(q2), to_f64(q3), to_f64(q4), to_f64(q5), args.gd);
+            }
+        }
+        {
+            typedef typename std::conditional<C == 2, f2, float>::type XS;  // fp32 folded sums of the ab plane
+            XS x0v, x1, x2, x3, x4, x5;
+            if constexpr (C == 2) {
+                x0v = f2{wx[CTR], wx[CTR + 1]};
+                x1 = f2{wx[CTR + 1] + wx[CTR - 1], wx[CTR + 2] + wx[CTR]};
+                x2 = f2{wx[CTR + 2] + wx[CTR - 2], wx[CTR + 3] + wx[CTR - 1]};
+                x3 = f2{wx[CTR + 3] + wx[CTR - 3], wx[CTR + 4] + wx[CTR - 2]};
+                x4 = f2{wx[CTR + 4] + wx[CTR - 4], wx[CTR + 5] + wx[CTR - 3]};
+                x5 = f2{wx[CTR + 5] + wx[CTR - 5], wx[CTR + 6] + wx[CTR - 4]};
+            } else {
+                x0v = wx[CTR];
+                x1 = wx[CTR + 1] + wx[CTR - 1];
+                x2 = wx[CTR + 2] + wx[CTR - 2];
+                x3 = wx[CTR + 3] + wx[CTR - 3];
+                x4 = wx[CTR + 4] + wx[CTR - 4];
+                x5 = wx[CTR + 5] + wx[CTR - 5];
+            }
+            if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED)
+                blur_exact<FUSED>(accX, x0v, x1, x2, x3, x4, x5);
+            else if constexpr (MODE == MODE_FAST)
+                blur_separable(accX, x0v, x1, x2, x3, x4, x5, args.gf);
+            else
+                blur_separable(accX, to_f64(x0v), to_f64(x1), to_f64(x2), to_f64(x3), to_f64(x4), to_f64(x5), args.gd);
+        }
+
+        // ---- ring entry 0 is now the finished output row y = r - 5 (sum_tile) ----
+        const int64_t y = r - 5;
+        if (y >= y0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int64_t x = x0 + (int64_t)C * lane + c;
+                if (x < W) {
+                    float vmap;
+                    if constexpr (DBL) {
+                        const double v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, accX[0], args.c1d, args.c2d);
+                        colsum[c] += v;
+                        vmap = (float)v;
+                    } else {
+                        float eab;
+                        if constexpr (C == 2) eab = (c == 0) ? accX[0].x : accX[0].y;
+                        else                  eab = accX[0];
+                        const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, eab, args.c1, args.c2);
+                        colsum[c] += (double)v;   // fp64 accumulation, src/ssim_avx.cpp:357-358
+                        vmap = v;
+                    }
+                    if constexpr (MAP)
+                        ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = vmap;
+                }
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // Strip total: lanes in a fixed butterfly order -> one fp64 partial per strip.
+    double tot = colsum[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) tot += colsum[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        tot += __shfl_down(tot, off, 64);
+    if (lane == 0)
+        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + blockIdx.y) * args.strips_x + blockIdx.x] = tot;
+}
+
+// Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then
+// a fixed LDS tree), so the result is independent of launch timing, batch split and GPU count.
+__global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, double* __restrict__ sums)
+{
+    __shared__ double sh[256];
+    const double* p = partials + (size_t)blockIdx.x * per_image;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < per_image; i += 256)
+        acc += p[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        sums[blockIdx.x] = sh[0];
+}
+
+template <int MODE, int C>
+hipError_t launch_mode(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
+{
+    const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
+    if (map) hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, true>), grid, block, 0, stream, ka);
+    else     hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, false>), grid, block, 0, stream, ka);
+    return hipGetLastError();
+}
+
+} // namespace
+
+static int columns_per_lane(int mode, int variant)
+{
+    if (mode == MODE_DOUBLE) return 1;
+    return variant == 1 ? 1 : 2;   // variant 1: one column per lane (lower VGPR use, more waves)
+}
+
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count)
+{
+    Geometry g;
+    g.width = width; g.height = height; g.count = count;
+    g.strip_w = 64 * columns_per_lane(mode, variant);
+    g.strips_x = (width + g.strip_w - 1) / g.strip_w;
+    if (strip_rows <= 0) {
+        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few
+        // waves per SIMD on every CU: aim for >= 8 strips per CU over the whole batch.
+        const uint64_t want = (uint64_t)(cu_count > 0 ? cu_count : 256) * 8;
+        uint32_t rows = 256;
+        while (rows > 32 && (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count < want)
+            rows >>= 1;
+        strip_rows = (int)rows;
+    }
+    if (strip_rows < 1) strip_rows = 1;
+    g.strip_rows = (uint32_t)strip_rows;
+    g.strips_y = height ? (height + g.strip_rows - 1) / g.strip_rows : 0;
+    return g;
+}
+
+hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* descs_dev, const PairDesc& single,
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end)
+{
+    if (geo.count == 0) return hipSuccess;
+    KArgs ka;
+    ka.single = single;
+    ka.descs = descs_dev;
+    ka.width = geo.width; ka.height = geo.height;
+    ka.strip_rows = geo.strip_rows; ka.strips_x = geo.strips_x; ka.strips_y = geo.strips_y;
+    ka.partials = partials;
+    // c1, c2: products in double, then cast (src/ssim.cpp:956-960)
+    ka.c1d = (0.01 * 255.0) * (0.01 * 255.0);
+    ka.c2d = (0.03 * 255.0) * (0.03 * 255.0);
+    ka.c1 = (float)ka.c1d;
+    ka.c2 = (float)ka.c2d;
+    // True 1-D Gaussian, sigma 1.5, normalised over the 11 taps.
+    {
+        double g[6], norm = 0.0;
+        for (int i = 0; i <= 5; ++i) {
+            g[i] = exp(-(double)(i * i) / (2.0 * 1.5 * 1.5));
+            norm += (i == 0) ? g[i] : 2.0 * g[i];
+        }
+        for (int i = 0; i <= 5; ++i) {
+            ka.gd[i] = g[i] / norm;
+            ka.gf[i] = (float)ka.gd[i];
+        }
+    }
+    bool map = single.map != nullptr;   // for batches the ABI guarantees all-or-none and mirrors it into `single`
+    if (geo.strips_x == 0 || geo.strips_y == 0) {
+        hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * geo.count, stream);
+        return e;
+    }
+    if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
+    hipError_t err;
+    const int C = columns_per_lane(mode, variant);
+    switch (mode) {
+    case MODE_EXACT:   err = (C == 2) ? launch_mode<MODE_EXACT, 2>(geo, ka, map, stream)   : launch_mode<MODE_EXACT, 1>(geo, ka, map, stream);   break;
+    case MODE_UNFUSED: err = (C == 2) ? launch_mode<MODE_UNFUSED, 2>(geo, ka, map, stream) : launch_mode<MODE_UNFUSED, 1>(geo, ka, map, stream); break;
+    case MODE_FAST:    err = (C == 2) ? launch_mode<MODE_FAST, 2>(geo, ka, map, stream)    : launch_mode<MODE_FAST, 1>(geo, ka, map, stream);    break;
+    case MODE_DOUBLE:  err = launch_mode<MODE_DOUBLE, 1>(geo, ka, map, stream); break;
+    default:           return hipErrorInvalidValue;
+    }
+    if (err != hipSuccess) return err;
+    if (ev_end) { hipError_t e = hipEventRecord(ev_end, stream); if (e != hipSuccess) return e; }
+    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count), dim3(256), 0, stream, partials, geo.partials_per_image(), sums);
+    return hipGetLastError();
+}
+
+} // namespace ssim_hip

@@ -1,0 +1,66 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def load_pair(entry):
+    w, h = entry["width"], entry["height"]
+    a = np.fromfile(os.path.join(GOLDEN, entry["a"]), np.uint8).reshape(h, w)
+    b = np.fromfile(os.path.join(GOLDEN, entry["b"]), np.uint8).reshape(h, w)
+    return a, b
+
+
+def image_entries(manifest):
+    return sorted(k for k in manifest if not k.startswith("_"))
+
+
+def f32_hex(v):
+    return "0x%08x" % np.float32(v).view(np.uint32)
+
+
+def ulp_diff(a, b):
+    """Distance in float32 ulps (both finite, same sign expected)."""
+    ia = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    ib = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ia - ib)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as o
+    o.oracle_lib()  # builds on demand
+    return o
+
+
+@pytest.fixture(scope="session")
+def lib():
+    import ssim_amd
+    return ssim_amd.load_library()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """A context on cuda:0.  Fails (never skips) when the extension or the device is missing."""
+    import ssim_amd
+    assert ssim_amd.device_count() > 0, "no HIP device visible: -m gpu tests need the MI355X"
+    ctx = ssim_amd.Context(0)
+    yield ctx
+    ctx.close()

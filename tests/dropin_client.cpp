@@ -1,0 +1,72 @@
+// A client written against the reference's public API only (rmgr/ssim.h, rmgr/ssim-openmp.h), the
+// way tests/rmgr-ssim-tests.cpp:228-336 and sample/rmgr-ssim-sample.cpp:78-101 of romigrou/ssim
+// use it: deprecated Params block, init_interleaved, compute_ssim(params), get_errno, map output.
+// Built with -std=c++98 and linked against librmgr-ssim-hip.so by tests/test_abi_cpu.py.
+//
+// usage: dropin_client a.u8 b.u8 width height channels   -> prints one line per channel
+#include <rmgr/ssim.h>
+#include <rmgr/ssim-openmp.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+static bool read_file(const char* path, std::vector<unsigned char>& out, size_t n)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    out.resize(n);
+    const size_t got = fread(&out[0], 1, n, f);
+    fclose(f);
+    return got == n;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 6) {
+        fprintf(stderr, "usage: %s a.u8 b.u8 width height channels\n", argv[0]);
+        return 2;
+    }
+    const int width = atoi(argv[3]), height = atoi(argv[4]), channels = atoi(argv[5]);
+    std::vector<unsigned char> a, b;
+    if (!read_file(argv[1], a, size_t(width) * height * channels) || !read_file(argv[2], b, size_t(width) * height * channels)) {
+        fprintf(stderr, "cannot read inputs\n");
+        return 2;
+    }
+    const rmgr::ssim::Version ver = rmgr::ssim::get_version();
+    printf("version %u.%u.%u %s\n", ver.major, ver.minor, ver.patch, ver.string);
+
+    std::vector<float> map(size_t(width) * height);
+    rmgr::ssim::Params params = rmgr::ssim::Params();   // value-initialised: all zero
+    params.width      = width;
+    params.height     = height;
+    params.ssimMap    = &map[0];
+    params.ssimStep   = 1;
+    params.ssimStride = width;
+    params.use_default_allocator();
+
+    for (int c = 0; c < channels; ++c) {
+        params.imgA.init_interleaved(&a[0], width * channels, channels, c);
+        params.imgB.init_interleaved(&b[0], width * channels, channels, c);
+#if defined(__GNUC__)
+    #pragma GCC diagnostic push
+    #pragma GCC diagnostic ignored "-Wdeprecated-declarations"
+#endif
+        const float ssim = rmgr::ssim::compute_ssim(params);
+        const int   err  = rmgr::ssim::get_errno(ssim);
+#if defined(__GNUC__)
+    #pragma GCC diagnostic pop
+#endif
+        if (err != 0) {
+            printf("channel %d errno %d\n", c, err);
+            continue;
+        }
+        float viaOmp = -1.0f;
+        const int rc = rmgr::ssim::compute_ssim_openmp(&viaOmp, params);
+        double mapSum = 0.0;
+        for (size_t i = 0; i < map.size(); ++i) mapSum += map[i];
+        union { float f; unsigned u; } bits, bitsOmp;
+        bits.f = ssim; bitsOmp.f = viaOmp;
+        printf("channel %d ssim 0x%08x openmp_rc %d openmp 0x%08x map_mean %.9f\n", c, bits.u, rc, bitsOmp.u, mapSum / double(map.size()));
+    }
+    return 0;
+}

@@ -1,0 +1,169 @@
+"""CPU: the drop-in boundary.  The C-ABI library loads without a GPU, exports every symbol the
+public headers declare, keeps the reference's struct layouts and validation order, and fails
+loudly (ENODEV) instead of computing anything on the CPU."""
+import ctypes
+import errno
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ssim_amd
+from conftest import GOLDEN, ROOT
+
+INCLUDE = os.path.join(ROOT, "include")
+
+
+def declared_c_functions():
+    names = set()
+    for h in ("ssim.h", "ssim-openmp.h", "ssim-hip.h"):
+        txt = open(os.path.join(INCLUDE, "rmgr", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names.update(re.findall(r"\b(rmgr_ssim_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_everything_the_headers_declare(lib):
+    declared = declared_c_functions()
+    assert declared == set(ssim_amd.C_SYMBOLS), declared ^ set(ssim_amd.C_SYMBOLS)
+    for name in sorted(declared) + ssim_amd.CXX_SYMBOLS:
+        assert hasattr(lib, name), "missing export " + name
+
+
+def test_struct_layouts_match_reference_abi():
+    # LP64 layout of include/rmgr/ssim.h:469-533 of the reference
+    assert ctypes.sizeof(ssim_amd.Version) == 24
+    assert ctypes.sizeof(ssim_amd.ImgParams) == 24
+    assert ctypes.sizeof(ssim_amd.Params) == 96
+    assert ssim_amd.Params.imgA.offset == 8 and ssim_amd.Params.imgB.offset == 32
+    assert ssim_amd.Params.ssimMap.offset == 56 and ssim_amd.Params.ssimStep.offset == 64
+    assert ssim_amd.Params.ssimStride.offset == 72 and ssim_amd.Params.alloc.offset == 80 and ssim_amd.Params.dealloc.offset == 88
+    assert ctypes.sizeof(ssim_amd.ThreadPool) == 24
+
+
+def test_struct_layouts_as_compiled(tmp_path):
+    src = tmp_path / "layout.c"
+    src.write_text("""
+#include <rmgr/ssim.h>
+#include <rmgr/ssim-openmp.h>
+#include <rmgr/ssim-hip.h>
+#include <rmgr/ssim-version.h>
+#include <stdio.h>
+int main(void) {
+    printf("%lu %lu %lu %lu %lu %lu %lu\\n", (unsigned long)sizeof(rmgr_ssim_Version), (unsigned long)sizeof(rmgr_ssim_ImgParams),
+           (unsigned long)sizeof(rmgr_ssim_Params), (unsigned long)sizeof(rmgr_ssim_ThreadPool),
+           (unsigned long)offsetof(rmgr_ssim_Params, ssimMap), (unsigned long)offsetof(rmgr_ssim_Params, alloc),
+           (unsigned long)offsetof(rmgr_ssim_ThreadPool, threadCount));
+    return 0;
+}
+""")
+    exe = tmp_path / "layout"
+    # the public headers are C89-clean (reference: include/rmgr/ssim.h compiles as C)
+    subprocess.run(["gcc", "-std=c89", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["24", "24", "96", "24", "56", "80", "16"]
+
+
+@pytest.mark.parametrize("std", ["c++98", "c++11", "c++17"])
+def test_headers_compile_as_cxx(tmp_path, std):
+    src = tmp_path / "hdr.cpp"
+    src.write_text("#include <rmgr/ssim.h>\n#include <rmgr/ssim-openmp.h>\n#include <rmgr/ssim-hip.h>\n"
+                   "int main() { rmgr::ssim::GeneralParams p = rmgr::ssim::GeneralParams(); (void)p; return 0; }\n")
+    subprocess.run(["g++", "-std=" + std, "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", INCLUDE, str(src)], check=True)
+
+
+def test_version_kat():
+    # tests/rmgr-ssim-tests.cpp:510-517
+    assert ssim_amd.get_version() == (2, 1, 0, "2.1.0")
+
+
+def test_init_helpers_and_their_errors(lib):
+    ip = ssim_amd.ImgParams()
+    buf = (ctypes.c_uint8 * 64)()
+    base = ctypes.addressof(buf)
+    assert lib.rmgr_ssim_init_interleaved(ctypes.byref(ip), base, 48, 3, 2) == 0
+    assert (ip.topLeft, ip.step, ip.stride) == (base + 2, 3, 48)
+    assert lib.rmgr_ssim_init_interleaved(ctypes.byref(ip), base, 48, 3, 3) == errno.EINVAL   # src/ssim.cpp:168
+    assert lib.rmgr_ssim_init_interleaved(None, base, 48, 3, 0) == errno.EINVAL
+    assert lib.rmgr_ssim_init_interleaved(ctypes.byref(ip), None, 48, 3, 0) == errno.EINVAL
+    planes = (ctypes.c_void_p * 2)(base, base + 32)
+    strides = (ctypes.c_ssize_t * 2)(16, -16)
+    assert lib.rmgr_ssim_init_planar(ctypes.byref(ip), planes, strides, 1) == 0
+    assert (ip.topLeft, ip.step, ip.stride) == (base + 32, 1, -16)
+    assert lib.rmgr_ssim_init_planar(ctypes.byref(ip), None, strides, 0) == errno.EINVAL
+    assert lib.rmgr_ssim_init_planar(ctypes.byref(ip), planes, None, 0) == errno.EINVAL
+    p = ssim_amd.Params()
+    assert lib.rmgr_ssim_use_default_allocator(ctypes.byref(p)) == 0 and p.alloc and p.dealloc
+    assert lib.rmgr_ssim_use_default_allocator(None) == errno.EINVAL
+    assert lib.rmgr_ssim_get_version(None) == errno.EINVAL
+
+
+def test_validation_order_matches_reference(lib):
+    """src/ssim.cpp:962-978 and :1147-1151: all EINVAL cases are decided before any device work,
+    so they are observable without a GPU."""
+    a = np.zeros((8, 8), np.uint8)
+    out = ctypes.c_float()
+    good = ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), None, None) == errno.EINVAL
+    assert lib.rmgr_ssim_compute_ssim(None, ctypes.byref(good), None) == errno.EINVAL          # both outputs NULL
+    bad = ssim_amd.make_params(8, 8, None, 1, 8, a.ctypes.data, 1, 8)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(bad), None) == errno.EINVAL
+    bad = ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, None, 1, 8)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(bad), None) == errno.EINVAL
+
+    @ssim_amd.api.ThreadPoolFct
+    def dispatch(ctx, fct, args, threads, jobs):
+        return 0
+    tp = ssim_amd.ThreadPool(dispatch, None, 0)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(good), ctypes.byref(tp)) == errno.EINVAL   # threadCount == 0
+    assert lib.rmgr_ssim_hip_finalize(1, None, 8, 8, None) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_enqueue_batch(None, 1, ctypes.byref(good), None) == errno.EINVAL
+
+
+def test_finalize_is_the_reference_mean():
+    # float(sum / double(width*height)) with the 32-bit product, src/ssim.cpp:1102
+    sums = np.array([14989246.104541957, 0.0, 3.0])
+    out = ssim_amd.finalize(sums, 4096, 4096)
+    assert out[0].view(np.uint32) == 0x3f64b7be
+    assert out[1] == 0.0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wrapped = ssim_amd.finalize(np.array([65536.0]), 65536, 65537)   # 65536*65537 mod 2^32 = 65536
+    assert wrapped[0] == np.float32(1.0)
+
+
+def has_gpu():
+    return ssim_amd.device_count() > 0
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_no_device_fails_loudly_never_computes():
+    a = np.full((32, 32), 9, np.uint8)
+    with pytest.raises(ssim_amd.SsimError) as ei:
+        ssim_amd.compute_ssim(a, a)
+    assert ei.value.errno == errno.ENODEV
+    with pytest.raises(ssim_amd.SsimError) as ei:
+        ssim_amd.Context(0)
+    assert ei.value.errno == errno.ENODEV
+
+
+def build_dropin_client(tmp_path):
+    exe = tmp_path / "dropin_client"
+    libdir = os.path.dirname(ssim_amd.LIB_PATH)
+    subprocess.run(["g++", "-std=c++98", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE,
+                    os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe),
+                    "-L", libdir, "-lrmgr-ssim-hip", "-Wl,-rpath," + libdir], check=True)
+    return str(exe)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_reference_style_client_links_and_reports_enodev(tmp_path, manifest):
+    """A C++98 program written against the reference's API links against the library unchanged."""
+    exe = build_dropin_client(tmp_path)
+    il = manifest["_interleaved"]
+    out = subprocess.run([exe, os.path.join(GOLDEN, il["a"]), os.path.join(GOLDEN, il["b"]), str(il["width"]), str(il["height"]), "3"],
+                         check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "version 2.1.0 2.1.0"
+    assert out[1:] == ["channel %d errno %d" % (c, errno.ENODEV) for c in range(3)]

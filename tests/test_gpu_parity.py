@@ -1,0 +1,348 @@
+"""GPU: parity of the HIP path (through the C ABI) with the oracle and the committed golden
+vectors.  MODE_EXACT must reproduce the reference's FMA path bit for bit per pixel; the global
+value is float(fp64 sum / N) where only the fp64 summation ORDER differs from the reference
+(SURVEY.md A.3), so it is required bit-equal on the goldens and within 1 float ulp elsewhere.
+north_star tolerance (global 1.5e-6, per-pixel 6.3e-4) is therefore met with margin zero-to-tiny.
+"""
+import ctypes
+import errno
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ssim_amd
+from conftest import GOLDEN, f32_hex, image_entries, load_pair, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def assert_same_map(got, want, what):
+    bad = np.count_nonzero(got.view(np.uint32) != want.view(np.uint32))
+    assert bad == 0, "%s: %d of %d pixels differ (max |d| %.3g)" % (what, bad, got.size, np.abs(got - want).max())
+
+
+def test_extension_is_loaded_and_device_is_gfx950(gpu_ctx):
+    d = gpu_ctx.describe()
+    assert "gfx950" in d, d
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_golden_fixtures_exact_mode(gpu_ctx, manifest, variant):
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    gpu_ctx.set_tuning(0, variant)
+    for name in image_entries(manifest):
+        ent = manifest[name]
+        a, b = load_pair(ent)
+        v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        assert sha(m) == ent["fma"]["map_sha256"], name
+        assert f32_hex(v) == ent["fma"]["ssim_hex"], (name, float(v), ent["fma"]["ssim"])
+        v2, _ = gpu_ctx.ssim_planes(a, b, want_map=False)
+        assert f32_hex(v2) == f32_hex(v), name
+    gpu_ctx.set_tuning(0, 0)
+
+
+def test_golden_fixtures_unfused_mode(gpu_ctx, manifest):
+    """The reference's AVX/SSE/generic arithmetic (separately rounded multiply-add)."""
+    gpu_ctx.set_mode(ssim_amd.MODE_UNFUSED)
+    try:
+        for name in image_entries(manifest):
+            ent = manifest[name]
+            a, b = load_pair(ent)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            assert sha(m) == ent["avx"]["map_sha256"], name
+            assert f32_hex(v) == ent["avx"]["ssim_hex"], name
+    finally:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+
+
+def test_reference_test_tolerances_vs_naive(gpu_ctx, manifest):
+    """What tests/rmgr-ssim-tests.cpp asserts of an implementation: global within 2e-6 and every
+    pixel within 1e-3 of the naive double oracle (:98-104, :310-326), on its einstein set."""
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    for name in image_entries(manifest):
+        ent = manifest[name]
+        if "map" not in ent["naive_f64"]:
+            continue
+        a, b = load_pair(ent)
+        v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        nmap = np.load(os.path.join(GOLDEN, ent["naive_f64"]["map"]))
+        assert abs(float(v) - float(ent["naive_f64"]["ssim"])) < 2e-6, name
+        assert np.abs(m.astype(np.float64) - nmap).max() < 1e-3, name
+
+
+SIZES = [(1, 1), (1, 37), (37, 1), (3, 200), (200, 3), (10, 10), (11, 11), (63, 255), (64, 256), (65, 257),
+         (129, 128), (127, 129), (130, 600), (300, 301)]
+
+
+@pytest.mark.parametrize("variant,strip_rows", [(0, 0), (0, 7), (0, 64), (1, 0), (1, 33)])
+def test_random_and_ragged_sizes_vs_oracle(gpu_ctx, oracle, variant, strip_rows):
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    gpu_ctx.set_tuning(strip_rows, variant)
+    rng = np.random.default_rng(99)
+    try:
+        for (h, w) in SIZES:
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            b = np.clip(a.astype(np.int32) + rng.integers(-25, 26, (h, w)), 0, 255).astype(np.uint8)
+            if (h + w) % 3 == 0:
+                b = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            ov, osum, om = oracle.ssim_f32(a, b, want_map=True, threads=4)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            assert_same_map(m, om, "%dx%d" % (w, h))
+            assert ulp_diff(v, ov) <= 1, (w, h, float(v), float(ov))
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+
+
+def test_flat_black_white_images(gpu_ctx, oracle):
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    for va, vb in ((0, 0), (255, 255), (0, 255), (17, 18)):
+        a = np.full((70, 300), va, np.uint8)
+        b = np.full((70, 300), vb, np.uint8)
+        ov, _, om = oracle.ssim_f32(a, b, want_map=True)
+        v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        assert_same_map(m, om, (va, vb))
+        assert f32_hex(v) == f32_hex(ov)
+
+
+def device_params(ctx, keep, a_arr, a_off, a_step, a_stride, b_arr, b_off, b_step, b_stride, w, h, map_floats=0, map_off=0, map_step=1, map_stride=None):
+    da, db = ctx.upload(a_arr), ctx.upload(b_arr)
+    keep += [da, db]
+    dm = None
+    if map_floats:
+        dm = ctx.alloc(4 * map_floats)
+        dm.upload(np.full(map_floats, -7.0, np.float32))
+        keep.append(dm)
+    p = ssim_amd.make_params(w, h, da.ptr + a_off, a_step, a_stride, db.ptr + b_off, b_step, b_stride,
+                             (dm.ptr + 4 * map_off) if dm else None, map_step, map_stride)
+    return p, dm
+
+
+def test_interleaved_bottom_up_and_column_major_addressing(gpu_ctx, manifest):
+    """ImgParams semantics (reference ssim.h:481-499): pixel = topLeft + x*step + y*stride, any sign."""
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    il = manifest["_interleaved"]
+    w, h, ch = il["width"], il["height"], il["channels"]
+    A = np.fromfile(os.path.join(GOLDEN, il["a"]), np.uint8).reshape(h, w, ch)
+    B = np.fromfile(os.path.join(GOLDEN, il["b"]), np.uint8).reshape(h, w, ch)
+    keep = []
+    try:
+        for c, name in enumerate(il["per_channel"]):
+            want = manifest[name]["fma"]
+            # interleaved RGB, step 3 (init_interleaved, src/ssim.cpp:156-178)
+            p, dm = device_params(gpu_ctx, keep, A, c, ch, w * ch, B, c, ch, w * ch, w, h, map_floats=w * h)
+            v = gpu_ctx.compute_device(p)
+            assert f32_hex(v) == want["ssim_hex"], name
+            assert sha(dm.download(np.float32, (h, w))) == want["map_sha256"], name
+            # bottom-up: flipped storage, negative stride, map written bottom-up too
+            Af, Bf = np.ascontiguousarray(A[::-1]), np.ascontiguousarray(B[::-1])
+            p, dm = device_params(gpu_ctx, keep, Af, (h - 1) * w * ch + c, ch, -w * ch, Bf, (h - 1) * w * ch + c, ch, -w * ch, w, h,
+                                  map_floats=w * h, map_off=(h - 1) * w, map_step=1, map_stride=-w)
+            v = gpu_ctx.compute_device(p)
+            assert f32_hex(v) == want["ssim_hex"], name
+            assert sha(dm.download(np.float32, (h, w))[::-1]) == want["map_sha256"], name
+            # column-major storage of the same channel: step = h, stride = 1; map with step 2
+            At, Bt = np.ascontiguousarray(A[:, :, c].T), np.ascontiguousarray(B[:, :, c].T)
+            p, dm = device_params(gpu_ctx, keep, At, 0, h, 1, Bt, 0, h, 1, w, h, map_floats=2 * w * h, map_step=2, map_stride=2 * w)
+            v = gpu_ctx.compute_device(p)
+            assert f32_hex(v) == want["ssim_hex"], name
+            raw = dm.download(np.float32, (h, 2 * w))
+            assert sha(np.ascontiguousarray(raw[:, 0::2])) == want["map_sha256"], name
+            assert np.all(raw[:, 1::2] == -7.0), "map elements between steps must stay untouched"
+    finally:
+        for d in keep:
+            d.free()
+
+
+def test_dropin_host_entry_points(gpu_ctx, manifest, lib):
+    """rmgr_ssim_compute_ssim / _openmp on HOST pointers (the unchanged reference call), incl. map
+    with ssimStep != 1, map-only, global-only, user allocator, and allocator failure -> ENOMEM."""
+    ent = manifest["bbb257x65_q50_ch1"]
+    a, b = load_pair(ent)
+    h, w = a.shape
+    want = np.load(os.path.join(GOLDEN, ent["fma"]["map"]))
+    v, m = ssim_amd.compute_ssim(a, b, want_map=True)
+    assert f32_hex(v) == ent["fma"]["ssim_hex"]
+    assert_same_map(m, want, "host map")
+    v, _ = ssim_amd.compute_ssim(a, b, want_map=False, openmp=True)
+    assert f32_hex(v) == ent["fma"]["ssim_hex"]
+    v, m = ssim_amd.compute_ssim(a, b, want_map=True, allocator=True)
+    assert f32_hex(v) == ent["fma"]["ssim_hex"]
+    assert_same_map(m, want, "host map, user allocator")
+
+    # map with step 3 and a padded stride, global not requested (ssim == NULL is legal with a map)
+    big = np.full((h, 3 * w + 5), -7.0, np.float32)
+    p = ssim_amd.make_params(w, h, a.ctypes.data, 1, w, b.ctypes.data, 1, w, big.ctypes.data, 3, 3 * w + 5)
+    assert lib.rmgr_ssim_compute_ssim(None, ctypes.byref(p), None) == 0
+    assert_same_map(np.ascontiguousarray(big[:, 0:3 * w:3]), want, "strided host map")
+    assert np.all(big[:, 1:3 * w:3] == -7.0) and np.all(big[:, 3 * w:] == -7.0)
+
+    # bottom-up host map
+    flip = np.zeros((h, w), np.float32)
+    p = ssim_amd.make_params(w, h, a.ctypes.data, 1, w, b.ctypes.data, 1, w, flip.ctypes.data + 4 * (h - 1) * w, 1, -w)
+    out = ctypes.c_float()
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None) == 0
+    assert_same_map(np.ascontiguousarray(flip[::-1]), want, "bottom-up host map")
+    assert f32_hex(out.value) == ent["fma"]["ssim_hex"]
+
+    # allocator that fails -> ENOMEM (src/ssim.cpp:1050-1052)
+    calls = []
+
+    @ssim_amd.api.AllocFct
+    def failing_alloc(size, alignment):
+        calls.append((size, alignment))
+        return None
+
+    @ssim_amd.api.DeallocFct
+    def dealloc(ptr):
+        calls.append("free")
+    p = ssim_amd.make_params(w, h, a.ctypes.data, 1, w, b.ctypes.data, 1, w)
+    p.alloc, p.dealloc = failing_alloc, dealloc
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None) == errno.ENOMEM
+    assert len(calls) == 1 and calls[0][1] == 64
+
+    # a thread pool is accepted and validated; the GPU grid does the work
+    @ssim_amd.api.ThreadPoolFct
+    def dispatch(ctx, fct, args, threads, jobs):
+        return 0
+    tp = ssim_amd.ThreadPool(dispatch, None, 8)
+    p = ssim_amd.make_params(w, h, a.ctypes.data, 1, w, b.ctypes.data, 1, w)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), ctypes.byref(tp)) == 0
+    assert f32_hex(out.value) == ent["fma"]["ssim_hex"]
+
+    # zero-sized image: not rejected by the reference, 0/0 -> NaN (SURVEY.md 8(b) "Errors")
+    p = ssim_amd.make_params(0, 0, a.ctypes.data, 1, w, b.ctypes.data, 1, w)
+    assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None) == 0
+    assert np.isnan(out.value)
+
+
+def test_reference_style_cxx98_client_on_gpu(tmp_path, manifest):
+    from test_abi_cpu import build_dropin_client
+    exe = build_dropin_client(tmp_path)
+    il = manifest["_interleaved"]
+    out = subprocess.run([exe, os.path.join(GOLDEN, il["a"]), os.path.join(GOLDEN, il["b"]), str(il["width"]), str(il["height"]), "3"],
+                         check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == "version 2.1.0 2.1.0"
+    for c, name in enumerate(il["per_channel"]):
+        want = manifest[name]["fma"]["ssim_hex"]
+        fields = out[1 + c].split()
+        assert fields[:4] == ["channel", str(c), "ssim", want], out[1 + c]
+        assert fields[4:8] == ["openmp_rc", "0", "openmp", want], out[1 + c]
+
+
+def test_batch_equals_single_calls(gpu_ctx, oracle):
+    """enqueue_batch: one launch over N pairs; per-image fp64 sums identical to N single calls."""
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    w, h, n = 333, 210, 7
+    keep, params = [], (ssim_amd.Params * n)()
+    singles = []
+    try:
+        for i in range(n):
+            a, b = oracle.synth_pair(w, h, 0x5EED + i)
+            da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+            keep += [da, db]
+            params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w)
+            singles.append(gpu_ctx.compute_device(params[i]))
+            ov, _, _ = oracle.ssim_f32(a, b, threads=4)
+            assert ulp_diff(singles[-1], ov) <= 1
+        sums = gpu_ctx.alloc(8 * n)
+        keep.append(sums)
+        gpu_ctx.enqueue_batch(params, n, sums.ptr)
+        gpu_ctx.enqueue_batch(params, n, sums.ptr)      # re-enqueue reuses the uploaded descriptor table
+        gpu_ctx.synchronize()
+        got = ssim_amd.finalize(sums.download(np.float64, (n,)), w, h)
+        assert [f32_hex(x) for x in got] == [f32_hex(x) for x in singles]
+        # a sub-batch gives the same per-image sums (what sharding over GPUs relies on)
+        sub = (ssim_amd.Params * 3)(params[4], params[1], params[6])
+        gpu_ctx.enqueue_batch(sub, 3, sums.ptr)
+        gpu_ctx.synchronize()
+        got3 = ssim_amd.finalize(sums.download(np.float64, (3,)), w, h)
+        assert [f32_hex(x) for x in got3] == [f32_hex(singles[i]) for i in (4, 1, 6)]
+        # mismatched sizes are refused
+        bad = (ssim_amd.Params * 2)(params[0], params[1])
+        bad[1].width = w - 1
+        with pytest.raises(ssim_amd.SsimError) as ei:
+            gpu_ctx.enqueue_batch(bad, 2, sums.ptr)
+        assert ei.value.errno == errno.EINVAL
+    finally:
+        for d in keep:
+            d.free()
+
+
+def test_full_size_known_answers_and_properties(gpu_ctx, oracle, manifest):
+    """BASELINE.json configs at full size: 4096^2 global (C2) and 8192^2 with map (C3), checked by
+    the reference's known answers, the oracle, and size-independent properties."""
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    keep = []
+    try:
+        # --- C2: 4096 x 4096, global only ---
+        ent = manifest["_synthetic"]["4096x4096_5eed"]
+        a, b = oracle.synth_pair(4096, 4096, 0x5EED)
+        assert int(a.sum(dtype=np.int64)) == ent["sumA"] and int(b.sum(dtype=np.int64)) == ent["sumB"]
+        da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+        keep += [da, db]
+        p = ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, db.ptr, 1, 4096)
+        v = gpu_ctx.compute_device(p)
+        assert f32_hex(v) == ent["fma"]["ssim_hex"], float(v)
+        # identity: SSIM(a, a) == 1 exactly
+        p_id = ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, da.ptr, 1, 4096)
+        assert f32_hex(gpu_ctx.compute_device(p_id)) == f32_hex(1.0)
+        # symmetry: every operation of the path is symmetric in (a, b)
+        p_sw = ssim_amd.make_params(4096, 4096, db.ptr, 1, 4096, da.ptr, 1, 4096)
+        assert f32_hex(gpu_ctx.compute_device(p_sw)) == f32_hex(v)
+        # strip height and kernel variant do not change the per-pixel values
+        dm = gpu_ctx.alloc(4 * 4096 * 4096)
+        keep.append(dm)
+        pm = ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, db.ptr, 1, 4096, dm.ptr, 1, 4096)
+        gpu_ctx.compute_device(pm)
+        base = dm.download(np.float32, (4096, 4096))
+        for rows, variant in ((32, 0), (100, 0), (0, 1)):
+            gpu_ctx.set_tuning(rows, variant)
+            assert f32_hex(gpu_ctx.compute_device(pm)) == f32_hex(v)
+            assert_same_map(dm.download(np.float32, (4096, 4096)), base, (rows, variant))
+        gpu_ctx.set_tuning(0, 0)
+        # oracle on the full image
+        ov, _, om = oracle.ssim_f32(a, b, want_map=True, threads=oracle.oracle_lib().oracle_max_threads())
+        assert f32_hex(ov) == ent["fma"]["ssim_hex"]
+        assert_same_map(base, om, "4096^2 map vs oracle")
+        # mirror: horizontally flipped inputs give the horizontally flipped map (fold is commutative)
+        da2, db2 = gpu_ctx.upload(a[:, ::-1]), gpu_ctx.upload(b[:, ::-1])
+        keep += [da2, db2]
+        pf = ssim_amd.make_params(4096, 4096, da2.ptr, 1, 4096, db2.ptr, 1, 4096, dm.ptr, 1, 4096)
+        gpu_ctx.compute_device(pf)
+        assert_same_map(dm.download(np.float32, (4096, 4096))[:, ::-1], base, "mirror")
+        for d in keep:
+            d.free()
+        keep = []
+        del base, om
+
+        # --- C3: 8192 x 8192 with map ---
+        ent = manifest["_synthetic"]["8192x8192_5eed"]
+        a, b = oracle.synth_pair(8192, 8192, 0x5EED)
+        assert int(a.sum(dtype=np.int64)) == ent["sumA"]
+        da, db, dm = gpu_ctx.upload(a), gpu_ctx.upload(b), gpu_ctx.alloc(4 * 8192 * 8192)
+        keep += [da, db, dm]
+        p = ssim_amd.make_params(8192, 8192, da.ptr, 1, 8192, db.ptr, 1, 8192, dm.ptr, 1, 8192)
+        v = gpu_ctx.compute_device(p)
+        assert f32_hex(v) == ent["fma"]["ssim_hex"], float(v)
+        m = dm.download(np.float32, (8192, 8192))
+        # global value is the mean of the map it wrote
+        assert abs(float(m.astype(np.float64).mean()) - float(v)) < 1e-7
+        # oracle on the four corners (each 600 x 600 incl. borders) -- the corner crops see the
+        # same pixels as the full image except within 5 px of the cut, which are excluded
+        for (ys, xs) in ((slice(0, 600), slice(0, 600)), (slice(0, 600), slice(8192 - 600, 8192)),
+                         (slice(8192 - 600, 8192), slice(0, 600)), (slice(8192 - 600, 8192), slice(8192 - 600, 8192))):
+            _, _, om = oracle.ssim_f32(np.ascontiguousarray(a[ys, xs]), np.ascontiguousarray(b[ys, xs]), want_map=True, threads=8)
+            gm = m[ys, xs]
+            iy = slice(0, 595) if ys.start == 0 else slice(5, 600)
+            ix = slice(0, 595) if xs.start == 0 else slice(5, 600)
+            assert_same_map(np.ascontiguousarray(gm[iy, ix]), np.ascontiguousarray(om[iy, ix]), "8192^2 corner")
+    finally:
+        for d in keep:
+            d.free()
