@@ -90,7 +90,7 @@ def main():
     import numpy as np
     import torch
     import ssim_amd
-    from ssim_amd import synth
+    from ssim_amd import sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,21 +113,21 @@ def main():
 
     P = args.pairs
     # --- resident synthetic batch: rank r owns global pairs r*P .. r*P+P-1 ---
+    first, _ = sharding.shard_range(rank, world, P)
     imgs = []
     params = (ssim_amd.Params * P)()
     for i in range(P):
-        a, b = synth.pair_torch(W, H, synth.BASE_SEED + rank * P + i, device=dev)
+        a, b = synth.pair_torch(W, H, synth.BASE_SEED + first + i, device=dev)
         imgs.append((a, b))
         params[i] = ssim_amd.make_params(W, H, a.data_ptr(), 1, W, b.data_ptr(), 1, W)
     sums_all = torch.zeros(world * P, dtype=torch.float64, device=dev)       # zero except this rank's slice
     work = torch.zeros_like(sums_all)
-    my_slice_ptr = sums_all.data_ptr() + 8 * rank * P
+    my_slice_ptr = sums_all.data_ptr() + 8 * first
 
     def step():
         ctx.enqueue_batch(params, P, my_slice_ptr)
-        if dist is not None:
-            work.copy_(sums_all)
-            dist.all_reduce(work)        # sum of per-image partial sums; other ranks contribute exact zeros
+        # all-reduce of the per-image partial sums; other ranks contribute exact zeros
+        return sharding.exchange_sums(sums_all, work, dist)
 
     def fence():
         torch.cuda.synchronize()
@@ -136,9 +136,9 @@ def main():
             torch.cuda.synchronize()
 
     # --- known-answer gate ---
-    step()
+    full = step()
     fence()
-    res = ssim_amd.finalize((work if dist is not None else sums_all).cpu().numpy(), W, H)
+    res = ssim_amd.finalize(full.cpu().numpy(), W, H)
     if int(res[0].view(np.uint32)) != KAT_PAIR0_HEX:
         raise SystemExit("known-answer check failed: pair 0 -> %r (0x%08x), want 0x%08x" % (float(res[0]), int(res[0].view(np.uint32)), KAT_PAIR0_HEX))
     if not np.all(np.isfinite(res)) or res.min() < 0.85 or res.max() > 0.95:

@@ -1,0 +1,76 @@
+"""CPU, 2 processes over gloo: the N>1 path of bench.py (shard by image, one all-reduce of the
+per-image fp64 sums, library-side finalize).  The per-image sums come from the oracle here -- it is
+the checker standing in for the device kernel, which needs the GPU; what is under test is that the
+sharding/exchange plumbing hands every rank the bit-identical vector a single process gets."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+W, H, PAIRS_PER_RANK = 96, 70, 3
+
+
+def image_sum(i):
+    import oracle
+    a, b = oracle.synth_pair(W, H, 0x5EED + i)
+    return oracle.ssim_f32(a, b)[1]
+
+
+def worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import ssim_amd
+    from ssim_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = sharding.shard_range(rank, world, PAIRS_PER_RANK)
+    sums_all = torch.zeros(world * PAIRS_PER_RANK, dtype=torch.float64)
+    work = torch.zeros_like(sums_all)
+    for i in range(first, last):
+        sums_all[i] = image_sum(i)
+    full = sharding.exchange_sums(sums_all, work, dist)
+    res = ssim_amd.finalize(full.numpy(), W, H)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_get_identical_complete_results(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import ssim_amd
+    single = ssim_amd.finalize(np.array([image_sum(i) for i in range(world * PAIRS_PER_RANK)]), W, H)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got.view(np.uint32), single.view(np.uint32)), r
+
+
+def test_shard_helpers():
+    from ssim_amd import sharding
+    assert sharding.shard_range(3, 8, 128) == (384, 512)
+    assert sharding.split_batch(1024, 8) == [(128 * r, 128 * (r + 1)) for r in range(8)]
+    parts = sharding.split_batch(10, 4)
+    assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    with pytest.raises(ValueError):
+        sharding.shard_range(2, 2, 1)
+
+
+def test_synthetic_generators_agree():
+    """ssim_amd.synth (numpy and torch twins, used by bench.py) == the oracle's C generator."""
+    sys.path.insert(0, ROOT)
+    import oracle
+    from ssim_amd import synth
+    for seed in (0x5EED, 0x5EEE, 0x5EED + 255):
+        a, b = oracle.synth_pair(301, 77, seed)
+        na, nb = synth.pair_numpy(301, 77, seed)
+        ta, tb = synth.pair_torch(301, 77, seed, device="cpu", rows_per_chunk=32)
+        assert np.array_equal(a, na) and np.array_equal(b, nb)
+        assert np.array_equal(a, ta.numpy()) and np.array_equal(b, tb.numpy())

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Minimal torch-free workload for rocprofv3 counter passes: the bench.py batch (N distinct 4096^2
+pairs resident in HBM, global SSIM only, or with the map) enqueued K times through the C ABI.
+
+usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [size=4096]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ssim_amd  # noqa: E402
+from ssim_amd import synth  # noqa: E402
+
+
+def main():
+    arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
+    pairs, steps, mode, want_map, size = arg(1, 8), arg(2, 5), arg(3, 0), arg(4, 0), arg(5, 4096)
+    ctx = ssim_amd.Context(0, mode=mode)
+    params = (ssim_amd.Params * pairs)()
+    keep = []
+    for i in range(pairs):
+        a, b = synth.pair_numpy(size, size, synth.BASE_SEED + i)
+        da, db = ctx.upload(a), ctx.upload(b)
+        dm = ctx.alloc(4 * size * size) if want_map else None
+        keep += [da, db, dm]
+        params[i] = ssim_amd.make_params(size, size, da.ptr, 1, size, db.ptr, 1, size, dm.ptr if dm else None, 1, size)
+    sums = ctx.alloc(8 * pairs)
+    for _ in range(steps):
+        ctx.enqueue_batch(params, pairs, sums.ptr)
+    ctx.synchronize()
+    res = ssim_amd.finalize(sums.download(np.float64, (pairs,)), size, size)
+    print("pairs %d steps %d mode %d map %d size %d: ssim[0] = %.9f (0x%08x)" % (pairs, steps, mode, want_map, size, res[0], res[0].view(np.uint32)))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
