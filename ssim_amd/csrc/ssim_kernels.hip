@@ -76,6 +76,14 @@ template <> struct VT<f2>     { typedef float  S; static __device__ __forceinlin
 template <> struct VT<double> { typedef double S; static __device__ __forceinline__ double splat(double k) { return k; } };
 template <> struct VT<d2>     { typedef double S; static __device__ __forceinline__ d2     splat(double k) { d2 v = {k, k}; return v; } };
 
+// Wave-uniform 64-bit value -> SGPR pair.
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ double to_f64(float v) { return (double)v; }
 __device__ __forceinline__ d2     to_f64(f2 v)    { d2 r = {(double)v.x, (double)v.y}; return r; }
 
@@ -213,16 +221,34 @@ __global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
     __shared__ __attribute__((aligned(16))) Slot ring[2];
 
     const int lane = threadIdx.x;
+
+    // XCD-aware strip order.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round
+    // robin; left to itself that puts horizontally adjacent strips -- which share their 2 x 8 halo
+    // columns and hence cache lines -- on different L2s.  Give each XCD a contiguous run of
+    // (strip_x, strip_y) instead (speed only; correctness does not depend on placement).
+    uint32_t sx = blockIdx.x, sy = blockIdx.y;
+    {
+        const uint32_t per_img = args.strips_x * args.strips_y;
+        if ((per_img & 7u) == 0) {
+            const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
+            const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
+            sy = swz / args.strips_x;
+            sx = swz - sy * args.strips_x;
+        }
+    }
+
+    // Everything in the descriptor is wave-uniform: keep it in SGPRs so that row addressing is
+    // scalar arithmetic (a descriptor fetched through a pointer would otherwise sit in VGPRs).
     PairDesc pd = args.single;
     if (args.descs) {
         const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
-        pd.a = gd->a; pd.a_step = gd->a_step; pd.a_stride = gd->a_stride;
-        pd.b = gd->b; pd.b_step = gd->b_step; pd.b_stride = gd->b_stride;
-        pd.map = gd->map; pd.map_step = gd->map_step; pd.map_stride = gd->map_stride;
+        pd.a = (const uint8_t*)uniform64((int64_t)gd->a); pd.a_step = uniform64(gd->a_step); pd.a_stride = uniform64(gd->a_stride);
+        pd.b = (const uint8_t*)uniform64((int64_t)gd->b); pd.b_step = uniform64(gd->b_step); pd.b_stride = uniform64(gd->b_stride);
+        pd.map = (float*)uniform64((int64_t)gd->map); pd.map_step = uniform64(gd->map_step); pd.map_stride = uniform64(gd->map_stride);
     }
     const int64_t W = args.width, H = args.height;
-    const int64_t x0 = (int64_t)blockIdx.x * STRIP_W;
-    const int64_t y0 = (int64_t)blockIdx.y * args.strip_rows;
+    const int64_t x0 = (int64_t)sx * STRIP_W;
+    const int64_t y0 = (int64_t)sy * args.strip_rows;
     const int64_t y_end = (y0 + args.strip_rows < H) ? y0 + args.strip_rows : H;
 
     // Per-lane staging columns: pixel p of the slot is image column clamp(x0 - PAD + p)
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
     for (int off = 32; off > 0; off >>= 1)
         tot += __shfl_down(tot, off, 64);
     if (lane == 0)
-        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + blockIdx.y) * args.strips_x + blockIdx.x] = tot;
+        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + sy) * args.strips_x + sx] = tot;
 }
 
 // Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then

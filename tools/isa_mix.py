@@ -24,12 +24,15 @@ def main():
             m = re.match(r'^(\.LBB\d+_\d+):', l)
             if m:
                 lab[m.group(1)] = i
+        # hot loop = the shortest backward-branch span holding >= 90% of the function's FMAs
+        isfma = [1 if re.match(r'\s*v_(pk_)?fma(c)?_f(32|64)', l) else 0 for l in lines]
+        total = sum(isfma)
         best = None
         for i, l in enumerate(lines):
-            m = re.search(r's_cbranch_\w+\s+(\.LBB\d+_\d+)', l)
+            m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
             if m and m.group(1) in lab and lab[m.group(1)] < i:
                 span = (lab[m.group(1)], i)
-                if best is None or span[1] - span[0] > best[1] - best[0]:
+                if sum(isfma[span[0]:span[1]]) >= 0.9 * total and (best is None or span[1] - span[0] < best[1] - best[0]):
                     best = span
         body = lines[best[0]:best[1] + 1] if best else lines
         c = collections.Counter()
