@@ -75,6 +75,19 @@ def cpu_baseline(sample_reps=12):
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
+def measured_traffic(mode, pairs):
+    """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json), scaled to
+    this batch; None when no measurement exists for the configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if mode == 0 and "exact_4096_nomap" in t:
+            return float(t["exact_4096_nomap"]["bytes_per_pair"]) * pairs
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,7 +225,7 @@ def main():
                        "mode": ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double", "unfused"][args.mode],
                        "pairs_per_gpu": P, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, P),
                          "kernel": "ssim_strip_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"},
