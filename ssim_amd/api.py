@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librmgr-ssim-hip.so")
+LIB_PATH = os.environ.get("RMGR_SSIM_LIB") or os.path.join(_HERE, "lib", "librmgr-ssim-hip.so")   # env override: A/B builds in tools/
 
 MODE_EXACT, MODE_FAST, MODE_DOUBLE, MODE_UNFUSED = 0, 1, 2, 3
 

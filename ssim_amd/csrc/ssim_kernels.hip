@@ -431,6 +431,217 @@ __global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
         ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + sy) * args.strips_x + sx] = tot;
 }
 
+// ---------------------------------------------------------------------------------------------
+// ssim_strip2_kernel: the tuned two-columns-per-lane kernel (fp32 modes).  Same arithmetic as
+// ssim_strip_kernel<MODE, 2, MAP>, restructured for VALU efficiency:
+//  * the ab plane is staged as pairs xx[p] = (ab[p], ab[p+1]) so that its folds are packed adds on
+//    naturally aligned register pairs like the two plane-pair streams (no v_pk_mov shuffles);
+//  * staging of row r+2 and the fetch of row r+3 sit behind the epilogue instead of in front of the blur.
+// Tried and dropped (measured on MI355X, round 1): refilling each plane's window for row r+1 right
+// after its last use (+36 VGPRs -> 1 wave/SIMD), unrolling the row loop over the two LDS slots
+// (312 registers), skipping the row sums halo rows cannot use (branches in the hot loop: -10 %).
+// ---------------------------------------------------------------------------------------------
+#ifndef SSIM2_REFILL
+#define SSIM2_REFILL 0   // refilling each plane's window right after its last use costs ~36 VGPRs (drops to 1 wave/SIMD)
+#endif
+
+struct Slot2 {
+    static constexpr int STRIP_W = 128, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
+    f2 ab[ROW_PX];   // (a, b)
+    f2 q[ROW_PX];    // (a*a, b*b)
+    f2 xx[ROW_PX];   // (ab[p], ab[p+1])
+};
+
+struct Window2 {
+    f2 ab[14], q[14], xx[12];
+};
+
+template <int MODE, bool MAP>
+__global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
+{
+    constexpr int STRIP_W = Slot2::STRIP_W, PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
+    constexpr int NLOAD = 3;
+    constexpr bool FUSED = (MODE != MODE_UNFUSED);
+    constexpr bool EXACT = (MODE == MODE_EXACT || MODE == MODE_UNFUSED);
+    static_assert(MODE != MODE_DOUBLE, "fp64 mode uses ssim_strip_kernel");
+
+    __shared__ __attribute__((aligned(16))) Slot2 ring[2];
+
+    const int lane = threadIdx.x;
+    uint32_t sx = blockIdx.x, sy = blockIdx.y;
+    {   // XCD-aware strip order (see ssim_strip_kernel)
+        const uint32_t per_img = args.strips_x * args.strips_y;
+        if ((per_img & 7u) == 0) {
+            const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
+            const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
+            sy = swz / args.strips_x;
+            sx = swz - sy * args.strips_x;
+        }
+    }
+    PairDesc pd = args.single;
+    if (args.descs) {
+        const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
+        pd.a = (const uint8_t*)uniform64((int64_t)gd->a); pd.a_step = uniform64(gd->a_step); pd.a_stride = uniform64(gd->a_stride);
+        pd.b = (const uint8_t*)uniform64((int64_t)gd->b); pd.b_step = uniform64(gd->b_step); pd.b_stride = uniform64(gd->b_stride);
+        pd.map = (float*)uniform64((int64_t)gd->map); pd.map_step = uniform64(gd->map_step); pd.map_stride = uniform64(gd->map_stride);
+    }
+    const int64_t W = args.width, H = args.height;
+    const int64_t x0 = (int64_t)sx * STRIP_W;
+    const int64_t y0 = (int64_t)sy * args.strip_rows;
+    const int64_t y_end = (y0 + args.strip_rows < H) ? y0 + args.strip_rows : H;
+
+    int     sp[NLOAD];
+    int64_t offA[NLOAD], offB[NLOAD];
+#pragma unroll
+    for (int t = 0; t < NLOAD; ++t) {
+        int p = lane + 64 * t;
+        p = p < ROW_PX ? p : ROW_PX - 1;
+        int64_t xg = x0 - PAD + p;
+        xg = xg < 0 ? 0 : (xg > W - 1 ? W - 1 : xg);
+        sp[t] = p;
+        offA[t] = xg * pd.a_step;
+        offB[t] = xg * pd.b_step;
+    }
+
+    uint8_t va[NLOAD], vb[NLOAD];
+    auto fetch = [&](int64_t r) {
+        const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+        const gptr_u8 ra = (gptr_u8)pd.a + ry * pd.a_stride;
+        const gptr_u8 rb = (gptr_u8)pd.b + ry * pd.b_stride;
+#pragma unroll
+        for (int t = 0; t < NLOAD; ++t) {
+            va[t] = ra[offA[t]];
+            vb[t] = rb[offB[t]];
+        }
+    };
+    auto stage = [&](Slot2& s) {
+        float* xf = reinterpret_cast<float*>(s.xx);
+#pragma unroll
+        for (int t = 0; t < NLOAD; ++t) {
+            const float a = (float)va[t], b = (float)vb[t];
+            const f2 ab = {a, b};
+            const float x = a * b;
+            const int p = sp[t];
+            s.ab[p] = ab;
+            s.q[p] = ab * ab;
+            xf[2 * p] = x;                          // xx[p].lo
+            xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
+        }
+    };
+    // Window reads, one plane at a time: this lane's two columns sit at slot pixels 2*lane+8, +9.
+    const int e = 2 * lane + PAD - 6;               // even: every read below is 16-byte aligned
+    auto load_ab = [&](const Slot2& s, Window2& w) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
+            w.ab[2 * t] = v.xy; w.ab[2 * t + 1] = v.zw;
+        }
+    };
+    auto load_q = [&](const Slot2& s, Window2& w) {
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+            w.q[2 * t] = u.xy;  w.q[2 * t + 1] = u.zw;
+        }
+    };
+    auto load_xx = [&](const Slot2& s, Window2& w) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+            w.xx[2 * t] = z.xy; w.xx[2 * t + 1] = z.zw;
+        }
+    };
+
+    f2 accAB[2][11], accQ[2][11], accX[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        accAB[0][k] = accAB[1][k] = accQ[0][k] = accQ[1][k] = accX[k] = f2{0.0f, 0.0f};
+    }
+    double colsum = 0.0;
+
+    // One source row: each plane's window is consumed (both columns), then immediately refilled
+    // from the OTHER slot with the next row's pixels, so the LDS latency of row r+1 hides behind
+    // the remaining streams of row r, the epilogue and the staging -- without extra registers.
+    auto blur_row = [&](Window2& w, const Slot2& next) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int m = 6 + c;
+            const f2 a1 = w.ab[m + 1] + w.ab[m - 1], a2 = w.ab[m + 2] + w.ab[m - 2], a3 = w.ab[m + 3] + w.ab[m - 3],
+                     a4 = w.ab[m + 4] + w.ab[m - 4], a5 = w.ab[m + 5] + w.ab[m - 5];
+            if constexpr (EXACT) {
+                blur_exact<FUSED>(accAB[c], w.ab[m], a1, a2, a3, a4, a5);
+            } else {
+                blur_separable(accAB[c], w.ab[m], a1, a2, a3, a4, a5, args.gf);
+            }
+        }
+        if (SSIM2_REFILL) load_ab(next, w);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int m = 6 + c;
+            const f2 q1 = w.q[m + 1] + w.q[m - 1], q2 = w.q[m + 2] + w.q[m - 2], q3 = w.q[m + 3] + w.q[m - 3],
+                     q4 = w.q[m + 4] + w.q[m - 4], q5 = w.q[m + 5] + w.q[m - 5];
+            if constexpr (EXACT) {
+                blur_exact<FUSED>(accQ[c], w.q[m], q1, q2, q3, q4, q5);
+            } else {
+                blur_separable(accQ[c], w.q[m], q1, q2, q3, q4, q5, args.gf);
+            }
+        }
+        if (SSIM2_REFILL) load_q(next, w);
+        // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); centre pair is index 6
+        const f2 x1 = w.xx[7] + w.xx[5], x2 = w.xx[8] + w.xx[4], x3 = w.xx[9] + w.xx[3], x4 = w.xx[10] + w.xx[2], x5 = w.xx[11] + w.xx[1];
+        if constexpr (EXACT) {
+            blur_exact<FUSED>(accX, w.xx[6], x1, x2, x3, x4, x5);
+        } else {
+            blur_separable(accX, w.xx[6], x1, x2, x3, x4, x5, args.gf);
+        }
+        if (SSIM2_REFILL) load_xx(next, w);
+    };
+    auto epilogue = [&](int64_t y) {    // ring entry 0 = finished output row y (sum_tile)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int64_t x = x0 + 2 * lane + c;
+            if (x < W) {
+                const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
+                colsum += (double)v;
+                if constexpr (MAP)
+                    ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
+            }
+        }
+    };
+    const int64_t r_begin = y0 - 5, r_end = y_end + 5;
+    fetch(r_begin);
+    stage(ring[0]);
+    fetch(r_begin + 1);
+    stage(ring[1]);
+    fetch(r_begin + 2);
+    __syncthreads();
+    Window2 w;
+    load_ab(ring[0], w);
+    load_q(ring[0], w);
+    load_xx(ring[0], w);
+
+    int cur = 0;
+#pragma unroll 1
+    for (int64_t r = r_begin; r < r_end; r += 1) {
+        // ---- even half: w holds row r (from ring[0]); row r+1 is staged in ring[1] ----
+        if (!SSIM2_REFILL) { load_ab(ring[cur], w); load_q(ring[cur], w); load_xx(ring[cur], w); }
+        blur_row(w, ring[cur ^ 1]);
+        if (r - 5 >= y0) epilogue(r - 5);
+        stage(ring[cur]);
+        fetch(r + 3);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);          // keep the two halves' windows from overlapping in registers
+        cur ^= 1;
+    }
+
+    double tot = colsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        tot += __shfl_down(tot, off, 64);
+    if (lane == 0)
+        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + sy) * args.strips_x + sx] = tot;
+}
+
 // Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then
 // a fixed LDS tree), so the result is independent of launch timing, batch split and GPU count.
 __global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, double* __restrict__ sums)
@@ -458,6 +669,15 @@ hipError_t launch_mode(const Geometry& geo, const KArgs& ka, bool map, hipStream
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
     if (map) hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, true>), grid, block, 0, stream, ka);
     else     hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, false>), grid, block, 0, stream, ka);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
+{
+    const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
+    if (map) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, true>), grid, block, 0, stream, ka);
+    else     hipLaunchKernelGGL((ssim_strip2_kernel<MODE, false>), grid, block, 0, stream, ka);
     return hipGetLastError();
 }
 
@@ -525,7 +745,17 @@ hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* de
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
     hipError_t err;
     const int C = columns_per_lane(mode, variant);
-    switch (mode) {
+    // variant 0: library default (the two-column kernels: ssim_strip_kernel<.,2,.> for the bit-exact modes,
+    // ssim_strip2_kernel for MODE_FAST, where the paired ab plane measured +4 %); 1: one column per lane;
+    // 2: ssim_strip_kernel<.,2,.> for every mode; 3: ssim_strip2_kernel for every fp32 mode.
+    const bool use2 = (mode != MODE_DOUBLE) && (variant == 3 || (variant == 0 && mode == MODE_FAST));
+    if (use2) {
+        switch (mode) {
+        case MODE_EXACT:   err = launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
+        case MODE_UNFUSED: err = launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
+        default:           err = launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
+        }
+    } else switch (mode) {
     case MODE_EXACT:   err = (C == 2) ? launch_mode<MODE_EXACT, 2>(geo, ka, map, stream)   : launch_mode<MODE_EXACT, 1>(geo, ka, map, stream);   break;
     case MODE_UNFUSED: err = (C == 2) ? launch_mode<MODE_UNFUSED, 2>(geo, ka, map, stream) : launch_mode<MODE_UNFUSED, 1>(geo, ka, map, stream); break;
     case MODE_FAST:    err = (C == 2) ? launch_mode<MODE_FAST, 2>(geo, ka, map, stream)    : launch_mode<MODE_FAST, 1>(geo, ka, map, stream);    break;

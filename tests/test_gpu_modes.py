@@ -20,8 +20,10 @@ GLOBAL_TOL = 1.5e-6
 PIXEL_TOL = 6.3e-4
 
 
-def test_fast_mode_within_documented_tolerance(gpu_ctx, manifest, oracle):
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_fast_mode_within_documented_tolerance(gpu_ctx, manifest, oracle, variant):
     gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+    gpu_ctx.set_tuning(0, variant)
     worst_g = worst_p = 0.0
     try:
         for name in image_entries(manifest):
@@ -42,6 +44,7 @@ def test_fast_mode_within_documented_tolerance(gpu_ctx, manifest, oracle):
             assert float(np.abs(m.astype(np.float64) - om.astype(np.float64)).max()) <= PIXEL_TOL
     finally:
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+        gpu_ctx.set_tuning(0, 0)
     print("fast mode worst global %.3g, worst per-pixel %.3g" % (worst_g, worst_p))
 
 
