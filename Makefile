@@ -9,11 +9,12 @@ ARCH    ?= gfx950
 SRC     := ssim_amd/csrc
 OUT     := ssim_amd/lib
 OBJ     := build/obj
+BIN     := ssim_amd/bin
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(SRC) -Wall -Wno-unused-function
 
 all: lib oracle
 
-lib: $(OUT)/librmgr-ssim-hip.so
+lib: $(OUT)/librmgr-ssim-hip.so $(BIN)/rmgr-ssim
 
 $(OBJ)/ssim_kernels.o: $(SRC)/ssim_kernels.hip $(SRC)/ssim_kernels.h
 	@mkdir -p $(OBJ)
@@ -32,11 +33,16 @@ $(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/s
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
+# The command-line tool: plain host C++ on top of the C ABI (reference: src/ssim-cli.cpp).
+$(BIN)/rmgr-ssim: $(SRC)/ssim_cli.cpp $(OUT)/librmgr-ssim-hip.so include/rmgr/ssim.h include/rmgr/ssim-hip.h
+	@mkdir -p $(BIN)
+	$(CXX) -std=c++98 -O2 -Wall -Wextra -Iinclude $< -o $@ -L$(OUT) -lrmgr-ssim-hip -Wl,-rpath,'$$ORIGIN/../lib'
+
 oracle:
 	$(MAKE) -C oracle all
 
 clean:
-	rm -rf build $(OUT)
+	rm -rf build $(OUT) $(BIN)
 	$(MAKE) -C oracle clean
 
 .PHONY: all lib oracle clean

@@ -33,6 +33,13 @@ W = H = 4096
 PAIRS_PER_GPU = 32
 KAT_PAIR0_HEX = 0x3f64b7be            # reference FMA path on seed 0x5EED (tests/golden/manifest.json)
 BYTES_PER_PIXEL = 2                   # algorithmic HBM bytes, global-only: one uint8 from each image
+# BASELINE.json configs as selectable workloads; the default ("4k") is the one the metric is quoted on.
+#   name: (width, height, pairs per GPU, write map, KAT of pair 0 = reference FMA float bits, description)
+WORKLOADS = {
+    "4k":     (4096, 4096, 32, False, 0x3f64b7be, "4096x4096 uint8 pairs (BASELINE.json configs[1] image), global SSIM only"),
+    "8k-map": (8192, 8192, 2, True, 0x3f64b5b4, "8192x8192 uint8 pairs with per-pixel SSIM map writeback (BASELINE.json configs[2])"),
+    "1080p":  (1920, 1080, 128, False, 0x3f64bb1f, "1920x1080 uint8 pairs, global SSIM only (BASELINE.json configs[3]: 1024 pairs over 8 GPUs = 128 per GPU)"),
+}
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # fp32 VALU work of MODE_EXACT per output pixel: 5 planes x (5 fold adds + 6 mul + 30 fma
 # + 10 ring adds) + 23 for the SSIM formula/divide/fp64 accumulate = 278 lane-ops
@@ -93,7 +100,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=PAIRS_PER_GPU, help="pairs per GPU per step")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (0: the workload's default)")
     ap.add_argument("--mode", type=int, default=0, help="0 exact (default), 1 fast separable")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
@@ -124,15 +132,19 @@ def main():
     ctx = ssim_amd.Context(local_rank, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
     ctx.set_tuning(args.strip_rows, args.variant)
 
-    P = args.pairs
+    global W, H, KAT_PAIR0_HEX, BYTES_PER_PIXEL
+    W, H, default_pairs, want_map, KAT_PAIR0_HEX, workload_desc = WORKLOADS[args.workload]
+    BYTES_PER_PIXEL = 6 if want_map else 2       # + one float per pixel when the map is written
+    P = args.pairs or default_pairs
     # --- resident synthetic batch: rank r owns global pairs r*P .. r*P+P-1 ---
     first, _ = sharding.shard_range(rank, world, P)
     imgs = []
     params = (ssim_amd.Params * P)()
     for i in range(P):
         a, b = synth.pair_torch(W, H, synth.BASE_SEED + first + i, device=dev)
-        imgs.append((a, b))
-        params[i] = ssim_amd.make_params(W, H, a.data_ptr(), 1, W, b.data_ptr(), 1, W)
+        m = torch.empty((H, W), dtype=torch.float32, device=dev) if want_map else None
+        imgs.append((a, b, m))
+        params[i] = ssim_amd.make_params(W, H, a.data_ptr(), 1, W, b.data_ptr(), 1, W, m.data_ptr() if want_map else None, 1, W)
     sums_all = torch.zeros(world * P, dtype=torch.float64, device=dev)       # zero except this rank's slice
     work = torch.zeros_like(sums_all)
     my_slice_ptr = sums_all.data_ptr() + 8 * first
@@ -156,6 +168,10 @@ def main():
         raise SystemExit("known-answer check failed: pair 0 -> %r (0x%08x), want 0x%08x" % (float(res[0]), int(res[0].view(np.uint32)), KAT_PAIR0_HEX))
     if not np.all(np.isfinite(res)) or res.min() < 0.85 or res.max() > 0.95:
         raise SystemExit("implausible batch results: %r" % res)
+    if want_map:   # the map that was written must average to the global value
+        mm = float(imgs[0][2].double().mean().item())
+        if abs(mm - float(res[0 if rank == 0 else first])) > 1e-6:
+            raise SystemExit("map mean %.9f disagrees with the global SSIM" % mm)
 
     for _ in range(args.warmup):
         step()
@@ -179,10 +195,30 @@ def main():
     ctx.set_profiling(False)
     kernel_avg_ms = kernel_ms / max(launches, 1)
 
+    # --- the opt-in separable mode on the same batch (kernel time only; never `value`) ---
+    other = {}
+    if args.mode == 0:
+        ctx.set_mode(1)
+        for _ in range(2):
+            ctx.enqueue_batch(params, P, my_slice_ptr)
+        ctx.synchronize()
+        ctx.set_profiling(True)
+        for _ in range(max(args.steps // 2, 3)):
+            ctx.enqueue_batch(params, P, my_slice_ptr)
+        ctx.synchronize()
+        n_f, ms_f = ctx.get_profile()
+        ctx.set_profiling(False)
+        ctx.set_mode(0)
+        other = {"mode": "fast (separable fp32, within tolerance, not bit-identical)", "kernel_avg_ms": round(ms_f / n_f, 4),
+                 "mpix_s": round(float(P) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1)}
+        ctx.enqueue_batch(params, P, my_slice_ptr)
+        ctx.synchronize()
+
     # --- single-pair latency/throughput (BASELINE.json configs[1] literally: one pair per call) ---
     single = {}
     if rank == 0:
-        one = (ssim_amd.Params * 1)(params[0])
+        p0 = ssim_amd.make_params(W, H, imgs[0][0].data_ptr(), 1, W, imgs[0][1].data_ptr(), 1, W)   # global-only
+        one = (ssim_amd.Params * 1)(p0)
         for _ in range(5):
             ctx.enqueue_batch(one, 1, my_slice_ptr)
         torch.cuda.synchronize()
@@ -193,7 +229,7 @@ def main():
         dt = (time.perf_counter() - t1) / 50
         t1 = time.perf_counter()
         for _ in range(20):
-            ctx.compute_device(params[0])
+            ctx.compute_device(p0)
         dts = (time.perf_counter() - t1) / 20
         # the unchanged reference call: HOST pointers, pageable memory, PCIe staging included
         ha, hb = imgs[0][0].cpu().numpy(), imgs[0][1].cpu().numpy()
@@ -220,18 +256,20 @@ def main():
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "4096x4096 uint8 pairs (BASELINE.json configs[1] image), global SSIM only, %d pairs per GPU per step, "
-                                   "sharded by image, %s" % (P, "RCCL all-reduce of per-image fp64 sums per step" if world > 1 else "single GPU, no collective"),
+            "config": {"workload": "%s, %d pairs per GPU per step, sharded by image, %s"
+                                   % (workload_desc, P, "RCCL all-reduce of per-image fp64 sums per step" if world > 1 else "single GPU, no collective"),
+                       "name": args.workload,
                        "mode": ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double", "unfused"][args.mode],
                        "pairs_per_gpu": P, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, P),
-                         "kernel": "ssim_strip_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, P) if args.workload == "4k" else None,
+                         "kernel": "ssim_strip2_kernel" if args.mode == 1 and args.variant in (0, 3) else "ssim_strip_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"},
             "valu": {"achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(valu / VALU_PEAK_TOPS, 4),
                      "ops_per_pixel": VALU_OPS_PER_PIXEL},
             "single_pair": single,
+            "fast_mode": other,
             "device": ctx.describe(),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,9 @@
  *   rmgr_ssim_hip_enqueue_batch        the caller-side loop over pairs    src/ssim-cli.cpp:197-210
  *                                      + per-thread fp64 partials         src/ssim.cpp:902-926
  *   rmgr_ssim_hip_finalize             the final mean                     src/ssim.cpp:1090-1103
+ *   rmgr_ssim_hip_compute_ssim_channels_host   the per-channel caller loop       src/ssim-cli.cpp:197-210, sample/rmgr-ssim-sample.cpp:82-101
+ *   rmgr_ssim_hip_compute_ssim_luminance_host  RGB -> BT.601 Y, then SSIM        src/ssim-cli.cpp:145-195
+ *   rmgr_ssim_hip_luminance_device             the conversion loop alone          src/ssim-cli.cpp:158-186
  *   rmgr_ssim_hip_set_mode             select_impl() / RMGR_SSIM_USE_DOUBLE   src/ssim.cpp:808-896, src/ssim_internal.h:26-37
  *
  * All functions return 0 or an errno value (EINVAL, ENOMEM, ECHILD = a HIP call failed,
@@ -76,6 +79,31 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32
 
 /* ssim[i] = float(sums[i] / double(width*height)) with the reference's 32-bit product (src/ssim.cpp:1102).  Host arrays. */
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT;
+
+/*
+ * All channels of one interleaved pair (host pointers, `channelCount` bytes per pixel, rows
+ * `strideA` / `strideB` bytes apart) in ONE staging copy and ONE launch: ssim[c] receives channel c's
+ * global SSIM.  ssimMap (or NULL) is an interleaved float map, channelCount floats per pixel, rows
+ * width*channelCount floats apart -- the layout rmgr-ssim writes (src/ssim-cli.cpp:108-127).
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_Context* ctx, float* ssim,
+                                                      const rmgr_uint8_t* imgA, ptrdiff_t strideA, const rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                                      rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t channelCount, float* ssimMap) RMGR_NOEXCEPT;
+
+/*
+ * SSIM of the BT.601 luminance of two interleaved images with >= 3 channels:
+ * Y = (19595 R + 38470 G + 7471 B + 32768) / 65536 in integers (src/ssim-cli.cpp:158-186), computed on
+ * the GPU from one staging copy.  ssimMap (or NULL): dense width x height floats.
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_Context* ctx, float* ssim,
+                                                       const rmgr_uint8_t* imgA, ptrdiff_t strideA, const rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                                       rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t channelCount, float* ssimMap) RMGR_NOEXCEPT;
+
+/* The conversion alone, device to device (asynchronous on the context's stream): dstY[x + y*dstStride]
+ * from src[x*srcStep + y*srcStride + {0,1,2}].  srcStep >= 3. */
+rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uint8_t* dstY, ptrdiff_t dstStride,
+                                            const rmgr_uint8_t* src, ptrdiff_t srcStep, ptrdiff_t srcStride,
+                                            rmgr_uint32_t width, rmgr_uint32_t height) RMGR_NOEXCEPT;
 
 /* Blocks until everything enqueued on the context's stream has finished. */
 rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;

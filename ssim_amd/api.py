@@ -62,6 +62,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
+    "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -109,6 +110,9 @@ def load_library(path=None):
         "rmgr_ssim_hip_memcpy_d2h": [vp, vp, vp, ctypes.c_size_t],
         "rmgr_ssim_hip_set_profiling": [vp, i32],
         "rmgr_ssim_hip_get_profile": [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)],
+        "rmgr_ssim_hip_compute_ssim_channels_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
+        "rmgr_ssim_hip_compute_ssim_luminance_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
+        "rmgr_ssim_hip_luminance_device": [vp, vp, c_pd, vp, c_pd, c_pd, u32, u32],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -175,6 +179,32 @@ def compute_ssim(a, b, want_map=False, openmp=False, allocator=False):
         _check("rmgr_ssim_compute_ssim_openmp", lib.rmgr_ssim_compute_ssim_openmp(ctypes.byref(out), ctypes.byref(p)))
     else:
         _check("rmgr_ssim_compute_ssim", lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None))
+    return np.float32(out.value), m
+
+
+def compute_ssim_channels(a, b, want_map=False):
+    """All channels of two interleaved H x W x C uint8 arrays in one launch (host pointers)."""
+    lib = load_library()
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    h, w, ch = a.shape
+    out = (ctypes.c_float * ch)()
+    m = np.empty((h, w, ch), np.float32) if want_map else None
+    _check("rmgr_ssim_hip_compute_ssim_channels_host", lib.rmgr_ssim_hip_compute_ssim_channels_host(
+        None, out, a.ctypes.data, w * ch, b.ctypes.data, w * ch, w, h, ch, m.ctypes.data if want_map else None))
+    return np.array(out[:], np.float32), m
+
+
+def compute_ssim_luminance(a, b, want_map=False):
+    """SSIM of the BT.601 luminance (computed on the GPU) of two interleaved H x W x C (C >= 3) uint8 arrays."""
+    lib = load_library()
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    h, w, ch = a.shape
+    out = ctypes.c_float()
+    m = np.empty((h, w), np.float32) if want_map else None
+    _check("rmgr_ssim_hip_compute_ssim_luminance_host", lib.rmgr_ssim_hip_compute_ssim_luminance_host(
+        None, ctypes.byref(out), a.ctypes.data, w * ch, b.ctypes.data, w * ch, w, h, ch, m.ctypes.data if want_map else None))
     return np.float32(out.value), m
 
 

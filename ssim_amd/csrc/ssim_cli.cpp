@@ -1,0 +1,566 @@
+// ssim_cli.cpp -- `rmgr-ssim`, the command-line front end.
+//
+// Same command line, output format and exit codes as the reference's tool (src/ssim-cli.cpp:74-83 help,
+// :130-213 per-channel / luminance / single-channel modes and their printf formats, :216-389 argument
+// handling and map export), on top of the C ABI of this repo:
+//   all channels  -> rmgr_ssim_hip_compute_ssim_channels_host   (one staging copy, one launch)
+//   -y luminance  -> rmgr_ssim_hip_compute_ssim_luminance_host  (BT.601 conversion on the GPU)
+//   -0..-3        -> rmgr_ssim_compute_ssim                      (the plain drop-in call)
+// The reference decodes images with stb_image, which it downloads at configure time and which is not
+// available here; this tool carries its own small codecs instead: PNG (8/16-bit, non-interlaced),
+// binary/ASCII PNM, uncompressed BMP and TGA for input; PNG, PNM, BMP, TGA and PFM for the map.
+#include <rmgr/ssim.h>
+#include <rmgr/ssim-hip.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <strings.h>
+#include <vector>
+
+namespace {
+
+typedef std::vector<unsigned char> Bytes;
+
+struct Image {
+    int width, height, channels;
+    Bytes px;   // interleaved, top-down
+    Image() : width(0), height(0), channels(0) {}
+};
+
+bool read_file(const char* path, Bytes& out)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) out.insert(out.end(), buf, buf + n);
+    fclose(f);
+    return true;
+}
+
+// ------------------------------------------------------------------------------ inflate (RFC 1951)
+struct BitReader {
+    const unsigned char* p; size_t n, pos; unsigned bitbuf; int bitcnt; bool bad;
+    BitReader(const unsigned char* d, size_t len) : p(d), n(len), pos(0), bitbuf(0), bitcnt(0), bad(false) {}
+    unsigned bits(int need) {
+        unsigned v = bitbuf;
+        while (bitcnt < need) {
+            if (pos >= n) { bad = true; return 0; }
+            v |= unsigned(p[pos++]) << bitcnt;
+            bitcnt += 8;
+        }
+        bitbuf = need < 32 ? v >> need : 0;
+        bitcnt -= need;
+        return need < 32 ? v & ((1u << need) - 1u) : v;
+    }
+};
+
+struct Huffman { short count[16]; short symbol[288]; };
+
+void build_huffman(Huffman& h, const short* lengths, int n)
+{
+    memset(h.count, 0, sizeof(h.count));
+    for (int i = 0; i < n; ++i) h.count[lengths[i]]++;
+    short offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + h.count[l];
+    for (int i = 0; i < n; ++i)
+        if (lengths[i]) h.symbol[offs[lengths[i]]++] = short(i);
+}
+
+int decode_symbol(BitReader& br, const Huffman& h)
+{
+    int code = 0, first = 0, index = 0;
+    for (int len = 1; len <= 15; ++len) {
+        code |= int(br.bits(1));
+        if (br.bad) return -1;
+        const int count = h.count[len];
+        if (code - count < first) return h.symbol[index + (code - first)];
+        index += count; first += count; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+bool inflate_codes(BitReader& br, Bytes& out, const Huffman& lit, const Huffman& dist)
+{
+    static const short lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
+    static const short lext[29]  = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+    static const short dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
+    static const short dext[30]  = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+    for (;;) {
+        int sym = decode_symbol(br, lit);
+        if (sym < 0) return false;
+        if (sym < 256) { out.push_back((unsigned char)sym); continue; }
+        if (sym == 256) return true;
+        sym -= 257;
+        if (sym >= 29) return false;
+        const int len = lbase[sym] + int(br.bits(lext[sym]));
+        const int ds = decode_symbol(br, dist);
+        if (ds < 0 || ds >= 30) return false;
+        const size_t d = size_t(dbase[ds]) + br.bits(dext[ds]);
+        if (br.bad || d > out.size()) return false;
+        for (int i = 0; i < len; ++i) out.push_back(out[out.size() - d]);
+    }
+}
+
+bool inflate(const unsigned char* data, size_t n, Bytes& out)
+{
+    BitReader br(data, n);
+    int last;
+    do {
+        last = int(br.bits(1));
+        const int type = int(br.bits(2));
+        if (br.bad) return false;
+        if (type == 0) {
+            br.bitbuf = 0; br.bitcnt = 0;
+            if (br.pos + 4 > n) return false;
+            const unsigned len = data[br.pos] | (data[br.pos + 1] << 8);
+            br.pos += 4;
+            if (br.pos + len > n) return false;
+            out.insert(out.end(), data + br.pos, data + br.pos + len);
+            br.pos += len;
+        } else if (type == 1 || type == 2) {
+            Huffman lit, dist;
+            short lengths[320];
+            if (type == 1) {
+                int i = 0;
+                for (; i < 144; ++i) lengths[i] = 8;
+                for (; i < 256; ++i) lengths[i] = 9;
+                for (; i < 280; ++i) lengths[i] = 7;
+                for (; i < 288; ++i) lengths[i] = 8;
+                build_huffman(lit, lengths, 288);
+                for (i = 0; i < 30; ++i) lengths[i] = 5;
+                build_huffman(dist, lengths, 30);
+            } else {
+                static const short order[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+                const int nlen = int(br.bits(5)) + 257, ndist = int(br.bits(5)) + 1, ncode = int(br.bits(4)) + 4;
+                if (br.bad || nlen > 286 || ndist > 30) return false;
+                short cl[19];
+                memset(cl, 0, sizeof(cl));
+                for (int i = 0; i < ncode; ++i) cl[order[i]] = short(br.bits(3));
+                Huffman lencode;
+                build_huffman(lencode, cl, 19);
+                int idx = 0;
+                while (idx < nlen + ndist) {
+                    int sym = decode_symbol(br, lencode);
+                    if (sym < 0) return false;
+                    if (sym < 16) { lengths[idx++] = short(sym); continue; }
+                    int prev = 0, rep;
+                    if (sym == 16) { if (idx == 0) return false; prev = lengths[idx - 1]; rep = 3 + int(br.bits(2)); }
+                    else if (sym == 17) rep = 3 + int(br.bits(3));
+                    else rep = 11 + int(br.bits(7));
+                    if (idx + rep > nlen + ndist) return false;
+                    while (rep--) lengths[idx++] = short(prev);
+                }
+                build_huffman(lit, lengths, nlen);
+                build_huffman(dist, lengths + nlen, ndist);
+            }
+            if (!inflate_codes(br, out, lit, dist)) return false;
+        } else return false;
+    } while (!last);
+    return true;
+}
+
+// ------------------------------------------------------------------------------ PNG
+unsigned be32(const unsigned char* p) { return (unsigned(p[0]) << 24) | (unsigned(p[1]) << 16) | (unsigned(p[2]) << 8) | p[3]; }
+
+bool decode_png(const Bytes& f, Image& img, std::string& err)
+{
+    if (f.size() < 33) { err = "truncated PNG"; return false; }
+    size_t pos = 8;
+    unsigned w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+    Bytes idat, plte;
+    while (pos + 12 <= f.size()) {
+        const unsigned len = be32(&f[pos]);
+        const char* tag = reinterpret_cast<const char*>(&f[pos + 4]);
+        if (pos + 12 + len > f.size()) { err = "truncated PNG chunk"; return false; }
+        const unsigned char* d = &f[pos + 8];
+        if (!memcmp(tag, "IHDR", 4)) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        else if (!memcmp(tag, "PLTE", 4)) plte.assign(d, d + len);
+        else if (!memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
+        else if (!memcmp(tag, "IEND", 4)) break;
+        pos += 12 + len;
+    }
+    if (interlace) { err = "interlaced PNG is not supported"; return false; }
+    if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) { err = "unsupported PNG bit depth"; return false; }
+    const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!samples || w == 0 || h == 0 || idat.size() < 6) { err = "unsupported or corrupt PNG"; return false; }
+    Bytes raw;
+    raw.reserve(size_t(h) * (size_t(w) * samples * depth / 8 + 2));
+    if (!inflate(&idat[2], idat.size() - 2, raw)) { err = "corrupt PNG data stream"; return false; }
+    const size_t bpp = std::max<size_t>(1, size_t(samples) * depth / 8), rowBytes = (size_t(w) * samples * depth + 7) / 8;
+    if (raw.size() < (rowBytes + 1) * h) { err = "short PNG data stream"; return false; }
+    Bytes prev(rowBytes, 0), cur(rowBytes);
+    img.width = int(w); img.height = int(h); img.channels = (ctype == 3) ? 3 : samples;
+    img.px.resize(size_t(w) * h * img.channels);
+    for (unsigned y = 0; y < h; ++y) {
+        const unsigned char* src = &raw[y * (rowBytes + 1)];
+        const int ft = src[0];
+        for (size_t i = 0; i < rowBytes; ++i) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+            int pred = 0;
+            if (ft == 1) pred = a; else if (ft == 2) pred = b; else if (ft == 3) pred = (a + b) >> 1;
+            else if (ft == 4) { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+            else if (ft != 0) { err = "bad PNG filter"; return false; }
+            cur[i] = (unsigned char)(src[1 + i] + pred);
+        }
+        unsigned char* dst = &img.px[size_t(y) * w * img.channels];
+        for (unsigned x = 0; x < w; ++x) {
+            for (int s = 0; s < samples; ++s) {
+                unsigned v;
+                if (depth == 8) v = cur[x * samples + s];
+                else if (depth == 16) v = cur[(x * samples + s) * 2];          // most significant byte
+                else { const unsigned bit = x * depth; v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u); if (ctype == 0) v = v * 255u / ((1u << depth) - 1u); }
+                if (ctype == 3) {
+                    if (3 * v + 2 >= plte.size()) { err = "bad PNG palette index"; return false; }
+                    dst[x * 3] = plte[3 * v]; dst[x * 3 + 1] = plte[3 * v + 1]; dst[x * 3 + 2] = plte[3 * v + 2];
+                } else dst[x * samples + s] = (unsigned char)v;
+            }
+        }
+        prev.swap(cur);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------ PNM / BMP / TGA input
+bool pnm_token(const Bytes& f, size_t& pos, int& v)
+{
+    for (;;) {
+        while (pos < f.size() && isspace(f[pos])) ++pos;
+        if (pos < f.size() && f[pos] == '#') { while (pos < f.size() && f[pos] != '\n') ++pos; continue; }
+        break;
+    }
+    if (pos >= f.size() || !isdigit(f[pos])) return false;
+    v = 0;
+    while (pos < f.size() && isdigit(f[pos])) v = v * 10 + (f[pos++] - '0');
+    return true;
+}
+
+bool decode_pnm(const Bytes& f, Image& img, std::string& err)
+{
+    const int kind = f[1] - '0';
+    if (kind != 2 && kind != 3 && kind != 5 && kind != 6) { err = "unsupported PNM type"; return false; }
+    size_t pos = 2;
+    int w, h, maxv;
+    if (!pnm_token(f, pos, w) || !pnm_token(f, pos, h) || !pnm_token(f, pos, maxv) || maxv <= 0 || maxv > 255) { err = "bad PNM header (only maxval <= 255)"; return false; }
+    img.width = w; img.height = h; img.channels = (kind == 3 || kind == 6) ? 3 : 1;
+    const size_t n = size_t(w) * h * img.channels;
+    img.px.resize(n);
+    if (kind >= 5) {
+        ++pos;   // single whitespace after maxval
+        if (pos + n > f.size()) { err = "truncated PNM"; return false; }
+        memcpy(&img.px[0], &f[pos], n);
+    } else {
+        for (size_t i = 0; i < n; ++i) { int v; if (!pnm_token(f, pos, v)) { err = "truncated PNM"; return false; } img.px[i] = (unsigned char)v; }
+    }
+    if (maxv != 255) for (size_t i = 0; i < n; ++i) img.px[i] = (unsigned char)(img.px[i] * 255 / maxv);
+    return true;
+}
+
+unsigned le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+unsigned le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | (unsigned(p[3]) << 24); }
+
+bool decode_bmp(const Bytes& f, Image& img, std::string& err)
+{
+    if (f.size() < 54) { err = "truncated BMP"; return false; }
+    const unsigned off = le32(&f[10]), hdr = le32(&f[14]);
+    const int w = int(le32(&f[18])), hs = int(le32(&f[22])), bpp = int(le16(&f[28]));
+    const unsigned comp = le32(&f[30]);
+    if ((comp != 0 && !(comp == 3 && bpp == 32)) || !(bpp == 8 || bpp == 24 || bpp == 32) || w <= 0 || hs == 0) { err = "unsupported BMP (need uncompressed 8/24/32 bpp)"; return false; }
+    const int h = hs < 0 ? -hs : hs;
+    const size_t stride = ((size_t(w) * bpp + 31) / 32) * 4;
+    if (off + stride * h > f.size()) { err = "truncated BMP"; return false; }
+    const unsigned char* pal = &f[14 + hdr];
+    img.width = w; img.height = h; img.channels = bpp == 32 ? 4 : 3;
+    img.px.resize(size_t(w) * h * img.channels);
+    for (int y = 0; y < h; ++y) {
+        const unsigned char* src = &f[off + stride * size_t(hs < 0 ? y : h - 1 - y)];
+        unsigned char* dst = &img.px[size_t(y) * w * img.channels];
+        for (int x = 0; x < w; ++x) {
+            if (bpp == 8) { const unsigned char* e = pal + 4 * src[x]; dst[3 * x] = e[2]; dst[3 * x + 1] = e[1]; dst[3 * x + 2] = e[0]; }
+            else { const int n = bpp / 8; dst[img.channels * x] = src[n * x + 2]; dst[img.channels * x + 1] = src[n * x + 1]; dst[img.channels * x + 2] = src[n * x]; if (n == 4) dst[4 * x + 3] = src[4 * x + 3]; }
+        }
+    }
+    return true;
+}
+
+bool decode_tga(const Bytes& f, Image& img, std::string& err)
+{
+    if (f.size() < 18) { err = "truncated TGA"; return false; }
+    const int idlen = f[0], type = f[2], w = int(le16(&f[12])), h = int(le16(&f[14])), bpp = f[16];
+    const bool topDown = (f[17] & 0x20) != 0;
+    if (!((type == 2 && (bpp == 24 || bpp == 32)) || (type == 3 && bpp == 8)) || f[1] != 0 || w <= 0 || h <= 0) { err = "unsupported TGA (need uncompressed true-colour or grey)"; return false; }
+    const int n = bpp / 8;
+    const size_t off = 18 + idlen;
+    if (off + size_t(w) * h * n > f.size()) { err = "truncated TGA"; return false; }
+    img.width = w; img.height = h; img.channels = n;
+    img.px.resize(size_t(w) * h * n);
+    for (int y = 0; y < h; ++y) {
+        const unsigned char* src = &f[off + size_t(topDown ? y : h - 1 - y) * w * n];
+        unsigned char* dst = &img.px[size_t(y) * w * n];
+        for (int x = 0; x < w; ++x) {
+            if (n == 1) dst[x] = src[x];
+            else { dst[n * x] = src[n * x + 2]; dst[n * x + 1] = src[n * x + 1]; dst[n * x + 2] = src[n * x]; if (n == 4) dst[4 * x + 3] = src[4 * x + 3]; }
+        }
+    }
+    return true;
+}
+
+bool load_image(const char* path, Image& img)
+{
+    Bytes f;
+    if (!read_file(path, f)) { fprintf(stderr, "Failed to open file \"%s\"\n", path); return false; }
+    std::string err = "unknown image format (supported: PNG, PNM, BMP, TGA)";
+    bool ok = false;
+    static const unsigned char pngSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    const char* ext = strrchr(path, '.');
+    if (f.size() >= 8 && !memcmp(&f[0], pngSig, 8)) ok = decode_png(f, img, err);
+    else if (f.size() >= 3 && f[0] == 'P' && f[1] >= '1' && f[1] <= '6') ok = decode_pnm(f, img, err);
+    else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') ok = decode_bmp(f, img, err);
+    else if (ext && !strcasecmp(ext, ".tga")) ok = decode_tga(f, img, err);
+    if (!ok) fprintf(stderr, "Failed to load image \"%s\":\n%s\n", path, err.c_str());
+    return ok;
+}
+
+// ------------------------------------------------------------------------------ map output
+unsigned crc32_of(const unsigned char* p, size_t n, unsigned crc)
+{
+    static unsigned table[256];
+    if (!table[1]) for (unsigned i = 0; i < 256; ++i) { unsigned c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 255] ^ (crc >> 8);
+    return ~crc;
+}
+
+void put_be32(Bytes& b, unsigned v) { b.push_back(v >> 24); b.push_back(v >> 16); b.push_back(v >> 8); b.push_back(v); }
+
+void png_chunk(FILE* f, const char* tag, const Bytes& data)
+{
+    Bytes c;
+    put_be32(c, unsigned(data.size()));
+    c.insert(c.end(), tag, tag + 4);
+    c.insert(c.end(), data.begin(), data.end());
+    put_be32(c, crc32_of(&c[4], c.size() - 4, 0));
+    fwrite(&c[0], 1, c.size(), f);
+}
+
+bool write_png(FILE* f, int w, int h, int ch, const unsigned char* px)
+{
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    fwrite(sig, 1, 8, f);
+    Bytes ihdr;
+    put_be32(ihdr, unsigned(w)); put_be32(ihdr, unsigned(h));
+    ihdr.push_back(8); ihdr.push_back(ch == 1 ? 0 : ch == 2 ? 4 : ch == 3 ? 2 : 6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    png_chunk(f, "IHDR", ihdr);
+    Bytes raw;                      // filter byte 0 + row
+    for (int y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), px + size_t(y) * w * ch, px + size_t(y + 1) * w * ch); }
+    Bytes z;                        // zlib stream of stored blocks
+    z.push_back(0x78); z.push_back(0x01);
+    unsigned a = 1, b = 0;
+    for (size_t i = 0; i < raw.size(); ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 255); z.push_back(n >> 8); z.push_back(~n & 255); z.push_back((~n >> 8) & 255);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        pos += n;
+        if (n == 0) break;
+    }
+    put_be32(z, (b << 16) | a);
+    png_chunk(f, "IDAT", z);
+    png_chunk(f, "IEND", Bytes());
+    return !ferror(f);
+}
+
+bool write_bmp(FILE* f, int w, int h, int ch, const unsigned char* px)
+{
+    const int stride = (w * 3 + 3) & ~3;
+    unsigned char hdr[54];
+    memset(hdr, 0, sizeof(hdr));
+    hdr[0] = 'B'; hdr[1] = 'M';
+    const unsigned size = 54 + unsigned(stride) * h;
+    hdr[2] = size; hdr[3] = size >> 8; hdr[4] = size >> 16; hdr[5] = size >> 24;
+    hdr[10] = 54; hdr[14] = 40;
+    hdr[18] = w; hdr[19] = w >> 8; hdr[20] = w >> 16; hdr[21] = w >> 24;
+    hdr[22] = h; hdr[23] = h >> 8; hdr[24] = h >> 16; hdr[25] = h >> 24;
+    hdr[26] = 1; hdr[28] = 24;
+    fwrite(hdr, 1, 54, f);
+    Bytes row(stride, 0);
+    for (int y = h - 1; y >= 0; --y) {
+        for (int x = 0; x < w; ++x) {
+            const unsigned char* s = px + (size_t(y) * w + x) * ch;
+            row[3 * x + 2] = s[0]; row[3 * x + 1] = ch >= 3 ? s[1] : s[0]; row[3 * x] = ch >= 3 ? s[2] : s[0];
+        }
+        fwrite(&row[0], 1, stride, f);
+    }
+    return !ferror(f);
+}
+
+bool write_tga(FILE* f, int w, int h, int ch, const unsigned char* px)
+{
+    unsigned char hdr[18];
+    memset(hdr, 0, sizeof(hdr));
+    const int n = (ch == 1) ? 1 : (ch == 4 ? 4 : 3);
+    hdr[2] = n == 1 ? 3 : 2; hdr[12] = w; hdr[13] = w >> 8; hdr[14] = h; hdr[15] = h >> 8; hdr[16] = 8 * n; hdr[17] = 0x20 | (n == 4 ? 8 : 0);
+    fwrite(hdr, 1, 18, f);
+    Bytes row(size_t(w) * n);
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            const unsigned char* s = px + (size_t(y) * w + x) * ch;
+            if (n == 1) row[x] = s[0];
+            else { row[n * x] = ch >= 3 ? s[2] : s[0]; row[n * x + 1] = ch >= 3 ? s[1] : s[0]; row[n * x + 2] = s[0]; if (n == 4) row[4 * x + 3] = s[3]; }
+        }
+        fwrite(&row[0], 1, row.size(), f);
+    }
+    return !ferror(f);
+}
+
+void print_help(FILE* file)
+{
+    fprintf(file, "Usage: rmgr-ssim [options] img1 img2 [map]\n"
+                  "Options:\n"
+                  "  -#  Compute SSIM only for channel #\n"
+                  "  -y  Compute SSIM on luminance\n"
+                  "      For images with <= 2 channels, only channel 0's SSIM will be computed\n"
+                  "      For images with >= 3 channels, first three channels are converted from RGB to Y\n\n");
+}
+
+int report(rmgr_int32_t rc)
+{
+    if (rc == ENODEV) fprintf(stderr, "No usable gfx950 (MI355X) device: this build of rmgr-ssim computes on the GPU only\n");
+    else fprintf(stderr, "SSIM computation failed: %s (errno %d)\n", strerror(rc), int(rc));
+    return EXIT_FAILURE;
+}
+
+// The three modes of the reference's compute_ssims() (src/ssim-cli.cpp:130-213), same printf formats.
+int compute_ssims(const Image& a, const Image& b, int onlyChannel, bool luminance, float* map, int mapChannels)
+{
+    const int w = a.width, h = a.height, ch = a.channels;
+    if (ch < 3 && luminance) onlyChannel = 0;
+    if (onlyChannel >= 0) {
+        rmgr_ssim_Params p;
+        memset(&p, 0, sizeof(p));
+        p.width = rmgr_uint32_t(w); p.height = rmgr_uint32_t(h);
+        rmgr_ssim_init_interleaved(&p.imgA, &a.px[0], ptrdiff_t(w) * ch, rmgr_uint32_t(ch), rmgr_uint32_t(onlyChannel));
+        rmgr_ssim_init_interleaved(&p.imgB, &b.px[0], ptrdiff_t(w) * ch, rmgr_uint32_t(ch), rmgr_uint32_t(onlyChannel));
+        p.ssimMap = map; p.ssimStep = mapChannels; p.ssimStride = ptrdiff_t(w) * mapChannels;
+        float ssim;
+        const rmgr_int32_t rc = rmgr_ssim_compute_ssim(&ssim, &p, NULL);
+        if (rc != 0) return report(rc);
+        printf("% 7.4f\n", ssim);
+    } else if (luminance) {
+        float ssim;
+        const rmgr_int32_t rc = rmgr_ssim_hip_compute_ssim_luminance_host(NULL, &ssim, &a.px[0], ptrdiff_t(w) * ch, &b.px[0], ptrdiff_t(w) * ch,
+                                                                          rmgr_uint32_t(w), rmgr_uint32_t(h), rmgr_uint32_t(ch), map);
+        if (rc != 0) return report(rc);
+        printf("% 7.4f\n", ssim);
+    } else {
+        std::vector<float> ssim(ch);
+        const rmgr_int32_t rc = rmgr_ssim_hip_compute_ssim_channels_host(NULL, &ssim[0], &a.px[0], ptrdiff_t(w) * ch, &b.px[0], ptrdiff_t(w) * ch,
+                                                                         rmgr_uint32_t(w), rmgr_uint32_t(h), rmgr_uint32_t(ch), map);
+        if (rc != 0) return report(rc);
+        float average = 0.0f;
+        for (int c = 0; c < ch; ++c) {
+            printf("Channel %u: % 7.4f\n", unsigned(c), ssim[c]);
+            average += ssim[c];
+        }
+        printf("Average  : % 7.4f\n", average / ch);
+    }
+    return EXIT_SUCCESS;
+}
+
+} // namespace
+
+int main(int argc, char* argv[])
+{
+    if (argc == 2 && (!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help"))) { print_help(stdout); return EXIT_SUCCESS; }
+    if (argc == 4 && !strcmp(argv[1], "--decode")) {
+        // test hook (not in the reference): decode an image with the built-in codecs, dump the raw pixels
+        Image img;
+        if (!load_image(argv[2], img)) return EXIT_FAILURE;
+        FILE* f = fopen(argv[3], "wb");
+        if (!f || fwrite(&img.px[0], 1, img.px.size(), f) != img.px.size()) return EXIT_FAILURE;
+        fclose(f);
+        printf("%d %d %d\n", img.width, img.height, img.channels);
+        return EXIT_SUCCESS;
+    }
+    if (argc < 3 || argc > 5) { print_help(stderr); return EXIT_FAILURE; }
+
+    int onlyChannel = -1, filesIndex = 1;
+    bool luminance = false;
+    if (argc >= 4 && argv[1][0] == '-') {
+        const char* opt = argv[1];
+        if (!strcmp(opt, "-0")) onlyChannel = 0;
+        else if (!strcmp(opt, "-1")) onlyChannel = 1;
+        else if (!strcmp(opt, "-2")) onlyChannel = 2;
+        else if (!strcmp(opt, "-3")) onlyChannel = 3;
+        else if (!strcmp(opt, "-y")) luminance = true;
+        else { fprintf(stderr, "Unknown option: %s\n", opt); return EXIT_FAILURE; }
+        filesIndex = 2;
+    }
+    const char* path1 = argv[filesIndex];
+    const char* path2 = argv[filesIndex + 1];
+    const char* mapPath = (argc - filesIndex == 3) ? argv[filesIndex + 2] : NULL;
+
+    Image img1, img2;
+    if (!load_image(path1, img1) || !load_image(path2, img2)) return EXIT_FAILURE;
+
+    std::vector<float> map;
+    int mapChannels = 0;
+    if (mapPath) {
+        mapChannels = (onlyChannel >= 0 || luminance) ? 1 : img1.channels;
+        map.resize(size_t(img1.width) * img1.height * mapChannels);
+    }
+
+    int retval = EXIT_FAILURE;
+    if (img1.width != img2.width || img1.height != img2.height)
+        fprintf(stderr, "Images do not have the same dimensions: %ux%u vs %ux%u\n", img1.width, img1.height, img2.width, img2.height);
+    else if (img1.channels != img2.channels)
+        fprintf(stderr, "Images do not have the same number of channels: %u vs %u\n", img1.channels, img2.channels);
+    else if (onlyChannel >= 0 && onlyChannel >= img1.channels)
+        fprintf(stderr, "Cannot compute SSIM for channel %u, images have only %u channels\n", onlyChannel, img1.channels);
+    else
+        retval = compute_ssims(img1, img2, onlyChannel, luminance, mapPath ? &map[0] : NULL, mapChannels);
+
+    if (retval == EXIT_SUCCESS && mapPath) {
+        const char* ext = strrchr(mapPath, '.');
+        enum { TGA, BMP, PNG, PFM, PNM } fmt = TGA;
+        if (!ext) fprintf(stderr, "Cannot deduce file format from extension, saving as tga\n");
+        else if (!strcasecmp(ext, ".bmp")) fmt = BMP;
+        else if (!strcasecmp(ext, ".png")) fmt = PNG;
+        else if (!strcasecmp(ext, ".tga")) fmt = TGA;
+        else if (!strcasecmp(ext, ".pgm") || !strcasecmp(ext, ".ppm") || !strcasecmp(ext, ".pnm")) fmt = PNM;
+        else if (!strcasecmp(ext, ".pfm")) {
+            fmt = PFM;
+            if (mapChannels != 1 && mapChannels != 3) { fprintf(stderr, "PFM images can only contain 1 or 3 channels but the map contains %d channels\n", mapChannels); retval = EXIT_FAILURE; }
+        } else retval = EXIT_FAILURE;
+        if (fmt == PNM && mapChannels != 1 && mapChannels != 3) { fprintf(stderr, "PNM images can only contain 1 or 3 channels but the map contains %d channels\n", mapChannels); retval = EXIT_FAILURE; }
+
+        if (retval == EXIT_SUCCESS) {
+            FILE* f = fopen(mapPath, "wb");
+            if (!f) { fprintf(stderr, "Failed to open file \"%s\" for writing\n", mapPath); return EXIT_FAILURE; }
+            const int w = img1.width, h = img1.height;
+            bool ok = true;
+            if (fmt == PFM) {
+                // raw floats, bottom row first, little endian (src/ssim-cli.cpp:355-374)
+                fprintf(f, "P%c\n%d %d\n-1.0\n", mapChannels == 1 ? 'f' : 'F', w, h);
+                const size_t stride = size_t(w) * mapChannels;
+                for (int y = h; --y >= 0;) ok = ok && fwrite(&map[y * stride], sizeof(float), stride, f) == stride;
+            } else {
+                Bytes map8(map.size());
+                for (size_t i = 0; i < map.size(); ++i) map8[i] = (unsigned char)(std::max(0.0f, map[i]) * 255.0f);   // src/ssim-cli.cpp:341-342
+                if (fmt == PNG) ok = write_png(f, w, h, mapChannels, &map8[0]);
+                else if (fmt == BMP) ok = write_bmp(f, w, h, mapChannels, &map8[0]);
+                else if (fmt == TGA) ok = write_tga(f, w, h, mapChannels, &map8[0]);
+                else { fprintf(f, "P%c\n%d %d\n255\n", mapChannels == 1 ? '5' : '6', w, h); ok = fwrite(&map8[0], 1, map8.size(), f) == map8.size(); }
+            }
+            if (!ok) { fprintf(stderr, "Error writing to file \"%s\"\n", mapPath); retval = EXIT_FAILURE; }
+            fclose(f);
+        }
+    }
+    return retval;
+}

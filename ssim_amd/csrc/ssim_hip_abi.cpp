@@ -441,6 +441,135 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     return 0;
 }
 
+} // extern "C"
+
+namespace {
+
+struct StagedPair {
+    rmgr_ssim_hip_Context* c;
+    std::unique_lock<std::mutex> guard;
+    uint8_t* a; uint8_t* b;       // device copies of the two interleaved images, rows `pitch` bytes apart
+    size_t pitch;
+};
+
+// Shared front half of the multi-channel entry points: context, validation, one H2D copy per image.
+int stage_interleaved(rmgr_ssim_hip_Context* c, StagedPair& sp, const void* out1, const void* out2,
+                      const uint8_t* imgA, ptrdiff_t strideA, const uint8_t* imgB, ptrdiff_t strideB,
+                      uint32_t width, uint32_t height, uint32_t channels)
+{
+    if ((out1 == NULL && out2 == NULL) || imgA == NULL || imgB == NULL || channels == 0) return EINVAL;
+    int rc = 0;
+    if (!c) {
+        c = default_context(&rc);
+        if (rc) return rc;
+        if (!c) return ENODEV;
+        sp.guard = std::unique_lock<std::mutex>(c->lock);
+    }
+    sp.c = c;
+    HIP_TRY(hipSetDevice(c->device));
+    sp.pitch = ((size_t)width * channels + 3) & ~(size_t)3;      // dword-aligned rows for the packed luminance path
+    const size_t bytes = sp.pitch * height + 4;
+    if ((rc = grow_device(c->stage_a, c->stage_a_cap, bytes))) return rc;
+    if ((rc = grow_device(c->stage_b, c->stage_b_cap, bytes))) return rc;
+    sp.a = c->stage_a; sp.b = c->stage_b;
+    if (width && height) {
+        // rows may be stored bottom-up (negative stride): copy row 0 first either way
+        HIP_TRY(hipMemcpy2DAsync(sp.a, sp.pitch, strideA >= 0 ? imgA : imgA + (ptrdiff_t)(height - 1) * strideA, (size_t)(strideA >= 0 ? strideA : -strideA),
+                                 (size_t)width * channels, height, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(sp.b, sp.pitch, strideB >= 0 ? imgB : imgB + (ptrdiff_t)(height - 1) * strideB, (size_t)(strideB >= 0 ? strideB : -strideB),
+                                 (size_t)width * channels, height, hipMemcpyHostToDevice, c->stream));
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* c, rmgr_uint8_t* dstY, ptrdiff_t dstStride,
+                                                       const rmgr_uint8_t* src, ptrdiff_t srcStep, ptrdiff_t srcStride,
+                                                       rmgr_uint32_t width, rmgr_uint32_t height) RMGR_NOEXCEPT
+{
+    if (!c || !dstY || !src || srcStep < 3) return EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(ssim_hip::launch_luminance(dstY, dstStride, src, srcStep, srcStride, width, height, c->stream));
+    return 0;
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_Context* ctx, float* ssim,
+                                                                 const rmgr_uint8_t* imgA, ptrdiff_t strideA, const rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                                                 rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t channels, float* ssimMap) RMGR_NOEXCEPT
+{
+    StagedPair sp;
+    int rc = stage_interleaved(ctx, sp, ssim, ssimMap, imgA, strideA, imgB, strideB, width, height, channels);
+    if (rc) return rc;
+    rmgr_ssim_hip_Context* c = sp.c;
+    const bool bottomA = strideA < 0, bottomB = strideB < 0;
+    const size_t mapFloats = (size_t)width * height * channels;
+    if (ssimMap && mapFloats && (rc = grow_device(c->stage_map, c->stage_map_cap, mapFloats))) return rc;
+    if ((rc = grow_device(c->sums, c->sums_cap, channels))) return rc;
+    if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, channels))) return rc;
+    std::vector<PairDesc> descs(channels);
+    for (uint32_t ch = 0; ch < channels; ++ch) {
+        PairDesc& d = descs[ch];
+        // the staged copies hold the rows in the order they were copied (row 0 of a bottom-up image last)
+        d.a = (bottomA ? sp.a + (size_t)(height ? height - 1 : 0) * sp.pitch : sp.a) + ch; d.a_step = channels; d.a_stride = bottomA ? -(int64_t)sp.pitch : (int64_t)sp.pitch;
+        d.b = (bottomB ? sp.b + (size_t)(height ? height - 1 : 0) * sp.pitch : sp.b) + ch; d.b_step = channels; d.b_stride = bottomB ? -(int64_t)sp.pitch : (int64_t)sp.pitch;
+        d.map = (ssimMap && mapFloats) ? c->stage_map + ch : NULL;
+        d.map_step = d.map ? channels : 0;
+        d.map_stride = d.map ? (int64_t)width * channels : 0;
+    }
+    if ((rc = enqueue(c, width, height, channels, descs.data(), ssimMap != NULL && mapFloats, c->sums))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * channels, hipMemcpyDeviceToHost, c->stream));
+    if (ssimMap && mapFloats)
+        HIP_TRY(hipMemcpyAsync(ssimMap, c->stage_map, sizeof(float) * mapFloats, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ssim)
+        for (uint32_t ch = 0; ch < channels; ++ch) ssim[ch] = mean_of(c->h_sums[ch], width, height);
+    return 0;
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_Context* ctx, float* ssim,
+                                                                  const rmgr_uint8_t* imgA, ptrdiff_t strideA, const rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                                                  rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t channels, float* ssimMap) RMGR_NOEXCEPT
+{
+    if (channels < 3) return EINVAL;
+    StagedPair sp;
+    int rc = stage_interleaved(ctx, sp, ssim, ssimMap, imgA, strideA, imgB, strideB, width, height, channels);
+    if (rc) return rc;
+    rmgr_ssim_hip_Context* c = sp.c;
+    // the Y planes live behind the staged RGB data of each image (rows in copy order: flip if bottom-up)
+    const size_t ypitch = ((size_t)width + 3) & ~(size_t)3;
+    const size_t rgbBytes = sp.pitch * height + 4, yBytes = ypitch * height + 4;
+    // grow WITHOUT losing the staged pixels: allocate the Y planes separately in the map staging area
+    const size_t mapFloats = (size_t)width * height;
+    const size_t needFloats = (ssimMap ? mapFloats : 0) + (2 * yBytes + 3) / 4 + 4;
+    if ((rc = grow_device(c->stage_map, c->stage_map_cap, needFloats))) return rc;
+    (void)rgbBytes;
+    uint8_t* ya = reinterpret_cast<uint8_t*>(c->stage_map + (ssimMap ? mapFloats : 0));
+    ya += (4 - (reinterpret_cast<uintptr_t>(ya) & 3u)) & 3u;
+    uint8_t* yb = ya + yBytes;
+    yb += (4 - (reinterpret_cast<uintptr_t>(yb) & 3u)) & 3u;
+    HIP_TRY(ssim_hip::launch_luminance(ya, (int64_t)ypitch, sp.a, channels, (int64_t)sp.pitch, width, height, c->stream));
+    HIP_TRY(ssim_hip::launch_luminance(yb, (int64_t)ypitch, sp.b, channels, (int64_t)sp.pitch, width, height, c->stream));
+    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
+    if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
+    PairDesc d;
+    const bool bottomA = strideA < 0, bottomB = strideB < 0;
+    d.a = bottomA ? ya + (size_t)(height ? height - 1 : 0) * ypitch : ya; d.a_step = 1; d.a_stride = bottomA ? -(int64_t)ypitch : (int64_t)ypitch;
+    d.b = bottomB ? yb + (size_t)(height ? height - 1 : 0) * ypitch : yb; d.b_step = 1; d.b_stride = bottomB ? -(int64_t)ypitch : (int64_t)ypitch;
+    d.map = (ssimMap && mapFloats) ? c->stage_map : NULL;
+    d.map_step = d.map ? 1 : 0;
+    d.map_stride = d.map ? width : 0;
+    if ((rc = enqueue(c, width, height, 1, &d, d.map != NULL, c->sums))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if (d.map)
+        HIP_TRY(hipMemcpyAsync(ssimMap, c->stage_map, sizeof(float) * mapFloats, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ssim) *ssim = mean_of(c->h_sums[0], width, height);
+    return 0;
+}
+
+extern "C" {
+
 rmgr_int32_t rmgr_ssim_hip_malloc(rmgr_ssim_hip_Context* c, void** p, size_t size) RMGR_NOEXCEPT
 {
     if (!c || !p) return EINVAL;

@@ -38,6 +38,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
 hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end);
 
+// BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.
+hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,
+                            uint32_t width, uint32_t height, hipStream_t stream);
+
 } // namespace ssim_hip
 
 #endif

@@ -683,6 +683,62 @@ hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStre
 
 } // namespace
 
+namespace {
+
+// Y = (R*19595 + G*38470 + B*7471 + 32768) / 65536: the integer BT.601 weights of the reference's
+// CLI (src/ssim-cli.cpp:158-186).  HBM-bound (3-4 B read, 1 B written per pixel): packed-RGB rows whose
+// addresses allow it are read as three dwords per four pixels and written as one dword; any other
+// layout takes the per-pixel path.
+__device__ __forceinline__ uint32_t bt601(uint32_t r, uint32_t g, uint32_t b)
+{
+    return (r * 19595u + g * 38470u + b * 7471u + 32768u) >> 16;
+}
+
+__global__ __launch_bounds__(256) void luminance_kernel(uint8_t* __restrict__ dst, int64_t dst_stride, const uint8_t* __restrict__ src,
+                                                       int64_t src_step, int64_t src_stride, uint32_t width, uint32_t height, int packed)
+{
+    const uint32_t y = blockIdx.y;
+    const uint8_t* srow = src + (int64_t)y * src_stride;
+    uint8_t* drow = dst + (int64_t)y * dst_stride;
+    const uint32_t quads = width >> 2;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (packed) {
+        if (i < quads) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(srow) + 3 * (size_t)i;
+            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+            const uint32_t y0 = bt601(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+            const uint32_t y1 = bt601(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+            const uint32_t y2 = bt601((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+            const uint32_t y3 = bt601((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+            reinterpret_cast<uint32_t*>(drow)[i] = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+        } else if (i == quads) {
+            for (uint32_t x = quads << 2; x < width; ++x) {
+                const uint8_t* px = srow + (int64_t)x * 3;
+                drow[x] = (uint8_t)bt601(px[0], px[1], px[2]);
+            }
+        }
+    } else {
+        for (uint32_t x = i; x < width; x += gridDim.x * blockDim.x) {
+            const uint8_t* px = srow + (int64_t)x * src_step;
+            drow[x] = (uint8_t)bt601(px[0], px[1], px[2]);
+        }
+    }
+}
+
+} // namespace
+
+hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,
+                            uint32_t width, uint32_t height, hipStream_t stream)
+{
+    if (width == 0 || height == 0) return hipSuccess;
+    const bool packed = src_step == 3 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)src_stride) & 3u) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_stride) & 3u) == 0;
+    const uint32_t items = packed ? (width >> 2) + 1 : width;
+    const dim3 grid((items + 255) / 256, height), block(256);
+    hipLaunchKernelGGL(luminance_kernel, grid, block, 0, stream, dst, dst_stride, src, src_step, src_stride, width, height, packed ? 1 : 0);
+    return hipGetLastError();
+}
+
 static int columns_per_lane(int mode, int variant)
 {
     if (mode == MODE_DOUBLE) return 1;
@@ -696,13 +752,15 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     if (strip_rows <= 0) {
-        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few
-        // waves per SIMD on every CU: aim for >= 8 strips per CU over the whole batch.
+        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per
+        // SIMD on every CU: aim for >= 8 strips per CU over the whole batch.  Then even the strips
+        // out (1080 rows -> 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
         const uint64_t want = (uint64_t)(cu_count > 0 ? cu_count : 256) * 8;
         uint32_t rows = 256;
         while (rows > 32 && (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count < want)
             rows >>= 1;
-        strip_rows = (int)rows;
+        const uint32_t ny = height ? (height + rows - 1) / rows : 1;
+        strip_rows = (int)(height ? (height + ny - 1) / ny : rows);
     }
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = (uint32_t)strip_rows;

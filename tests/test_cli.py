@@ -1,0 +1,218 @@
+"""The rmgr-ssim command-line tool (reference src/ssim-cli.cpp).
+
+CPU: the built-in image codecs decode what PIL encodes (PNG incl. the reference's own test images
+when present, PNM, BMP, TGA) and the argument handling mirrors the reference.
+GPU: printed values and written maps agree with the golden vectors / the oracle.
+"""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, f32_hex
+
+CLI = os.path.join(ROOT, "ssim_amd", "bin", "rmgr-ssim")
+
+
+def run(*args):
+    return subprocess.run([CLI] + list(args), capture_output=True, text=True)
+
+
+def write_png(path, arr, filter_type=1):
+    """Minimal PNG encoder (zlib from the stdlib) with a chosen row filter, to exercise the CLI's defilter code."""
+    arr = np.ascontiguousarray(arr)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    h, w, c = arr.shape
+    rows = []
+    prev = np.zeros((w, c), np.int16)
+    for y in range(h):
+        cur = arr[y].astype(np.int16)
+        left = np.vstack([np.zeros((1, c), np.int16), cur[:-1]])
+        upleft = np.vstack([np.zeros((1, c), np.int16), prev[:-1]])
+        if filter_type == 0:
+            pred = 0
+        elif filter_type == 1:
+            pred = left
+        elif filter_type == 2:
+            pred = prev
+        elif filter_type == 3:
+            pred = (left + prev) >> 1
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        rows.append(bytes([filter_type]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+        prev = cur
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[c]
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(b"".join(rows), 6)) + chunk(b"IEND", b""))
+
+
+def rgb_fixture(manifest):
+    il = manifest["_interleaved"]
+    w, h = il["width"], il["height"]
+    a = np.fromfile(os.path.join(GOLDEN, il["a"]), np.uint8).reshape(h, w, 3)
+    b = np.fromfile(os.path.join(GOLDEN, il["b"]), np.uint8).reshape(h, w, 3)
+    return a, b
+
+
+def test_cli_exists_and_prints_help():
+    r = run("-h")
+    assert r.returncode == 0 and r.stdout.startswith("Usage: rmgr-ssim [options] img1 img2 [map]")
+    r = run()
+    assert r.returncode != 0 and "Usage:" in r.stderr
+
+
+def test_codecs_roundtrip(tmp_path, manifest):
+    a, _ = rgb_fixture(manifest)
+    h, w, _ = a.shape
+    cases = {}
+    for ft in range(5):
+        p = str(tmp_path / ("f%d.png" % ft))
+        write_png(p, a, ft)
+        cases[p] = a
+    p = str(tmp_path / "gray.png")
+    write_png(p, a[:, :, 1], 4)
+    cases[p] = a[:, :, 1:2]
+    p = str(tmp_path / "rgba.png")
+    rgba = np.dstack([a, 255 - a[:, :, :1]])
+    write_png(p, rgba, 3)
+    cases[p] = rgba
+    p = str(tmp_path / "a.ppm")
+    open(p, "wb").write(b"P6\n# comment\n%d %d\n255\n" % (w, h) + a.tobytes())
+    cases[p] = a
+    p = str(tmp_path / "a.pgm")
+    open(p, "wb").write(b"P5 %d %d 255\n" % (w, h) + a[:, :, 0].tobytes())
+    cases[p] = a[:, :, :1]
+    p = str(tmp_path / "a_ascii.ppm")
+    open(p, "w").write("P3\n%d %d\n255\n" % (w, 2) + " ".join(str(v) for v in a[:2].ravel()) + "\n")
+    cases[p] = a[:2]
+    try:
+        from PIL import Image
+        for ext in ("png", "bmp", "tga"):
+            p = str(tmp_path / ("pil." + ext))
+            Image.fromarray(a).save(p)
+            cases[p] = a
+        p = str(tmp_path / "pil_gray.png")
+        Image.fromarray(a[:, :, 0]).save(p, optimize=True)
+        cases[p] = a[:, :, :1]
+    except ImportError:
+        pass
+    for path, want in cases.items():
+        out = str(tmp_path / "dump.raw")
+        r = run("--decode", path, out)
+        assert r.returncode == 0, (path, r.stderr)
+        ww, hh, cc = map(int, r.stdout.split())
+        got = np.fromfile(out, np.uint8).reshape(hh, ww, cc)
+        assert got.shape == want.shape and np.array_equal(got, want), path
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/tests/images"), reason="reference tree not present")
+def test_decodes_reference_test_pngs(tmp_path):
+    from PIL import Image
+    for name in ("einstein.png", "blur.png", "big_buck_bunny_360_07806.png"):
+        src = "/root/reference/tests/images/" + name
+        out = str(tmp_path / "d.raw")
+        r = run("--decode", src, out)
+        assert r.returncode == 0, r.stderr
+        w, h, c = map(int, r.stdout.split())
+        want = np.array(Image.open(src))
+        got = np.fromfile(out, np.uint8).reshape(h, w, c)
+        assert np.array_equal(got.reshape(want.shape), want), name
+
+
+def test_argument_errors(tmp_path, manifest):
+    a, b = rgb_fixture(manifest)
+    pa, pb, pg = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm"), str(tmp_path / "g.pgm")
+    h, w, _ = a.shape
+    open(pa, "wb").write(b"P6\n%d %d\n255\n" % (w, h) + a.tobytes())
+    open(pb, "wb").write(b"P6\n%d %d\n255\n" % (w - 1, h) + np.ascontiguousarray(b[:, :w - 1]).tobytes())
+    open(pg, "wb").write(b"P5\n%d %d\n255\n" % (w, h) + a[:, :, 0].tobytes())
+    assert "Unknown option" in run("-x", pa, pa).stderr
+    r = run(pa, pb)
+    assert r.returncode != 0 and "Images do not have the same dimensions: 257x65 vs 256x65" in r.stderr
+    r = run(pa, pg)
+    assert r.returncode != 0 and "Images do not have the same number of channels: 3 vs 1" in r.stderr
+    r = run("-3", pa, pa)
+    assert r.returncode != 0 and "Cannot compute SSIM for channel 3, images have only 3 channels" in r.stderr
+    r = run(str(tmp_path / "missing.png"), pa)
+    assert r.returncode != 0 and "Failed to open file" in r.stderr
+
+
+def bt601(img):
+    x = img.astype(np.uint32)
+    return ((x[:, :, 0] * 19595 + x[:, :, 1] * 38470 + x[:, :, 2] * 7471 + 32768) >> 16).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_cli_values_and_maps_on_gpu(tmp_path, manifest, oracle):
+    a, b = rgb_fixture(manifest)
+    h, w, _ = a.shape
+    pa, pb = str(tmp_path / "a.png"), str(tmp_path / "b.ppm")
+    write_png(pa, a, 4)
+    open(pb, "wb").write(b"P6\n%d %d\n255\n" % (w, h) + b.tobytes())
+    want = [np.uint32(int(manifest[n]["fma"]["ssim_hex"], 16)).view(np.float32) for n in manifest["_interleaved"]["per_channel"]]
+
+    # all channels + average (src/ssim-cli.cpp:197-210), PFM map with 3 channels
+    pfm = str(tmp_path / "map.pfm")
+    r = run(pa, pb, pfm)
+    assert r.returncode == 0, r.stderr
+    avg = np.float32(0)
+    for v in want:
+        avg = np.float32(avg + v)
+    lines = r.stdout.splitlines()
+    assert lines == ["Channel %u: % 7.4f" % (c, want[c]) for c in range(3)] + ["Average  : % 7.4f" % (avg / np.float32(3))]
+    raw = open(pfm, "rb").read()
+    header = b"PF\n%d %d\n-1.0\n" % (w, h)
+    assert raw.startswith(header)
+    m = np.frombuffer(raw[len(header):], np.float32).reshape(h, w, 3)[::-1]
+    for c, name in enumerate(manifest["_interleaved"]["per_channel"]):
+        ref = np.load(os.path.join(GOLDEN, manifest[name]["fma"]["map"])) if "map" in manifest[name]["fma"] else oracle.ssim_f32(a[:, :, c], b[:, :, c], want_map=True)[2]
+        assert np.array_equal(np.ascontiguousarray(m[:, :, c]).view(np.uint32), ref.view(np.uint32)), c
+
+    # single channel, 8-bit PGM map = uint8(max(0, v) * 255)  (src/ssim-cli.cpp:341-342)
+    pgm = str(tmp_path / "map.pgm")
+    r = run("-1", pa, pb, pgm)
+    assert r.returncode == 0 and r.stdout == "% 7.4f\n" % want[1]
+    ref = np.load(os.path.join(GOLDEN, manifest["bbb257x65_q50_ch1"]["fma"]["map"]))
+    raw = open(pgm, "rb").read()
+    header = b"P5\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(header)
+    got8 = np.frombuffer(raw[len(header):], np.uint8).reshape(h, w)
+    assert np.array_equal(got8, (np.maximum(ref, 0) * np.float32(255)).astype(np.uint8))
+
+    # luminance: integer BT.601 on the GPU, then SSIM; PNG map read back through the CLI's own decoder
+    ya, yb = bt601(a), bt601(b)
+    ov, _, om = oracle.ssim_f32(ya, yb, want_map=True)
+    png = str(tmp_path / "map.png")
+    r = run("-y", pa, pb, png)
+    assert r.returncode == 0 and r.stdout == "% 7.4f\n" % ov, (r.stdout, float(ov), r.stderr)
+    out = str(tmp_path / "map.raw")
+    r = run("--decode", png, out)
+    assert r.returncode == 0 and r.stdout.split() == [str(w), str(h), "1"]
+    assert np.array_equal(np.fromfile(out, np.uint8).reshape(h, w), (np.maximum(om, 0) * np.float32(255)).astype(np.uint8))
+
+    # the same through the C ABI bindings, bit-exact
+    import ssim_amd
+    lv, lm = ssim_amd.compute_ssim_luminance(a, b, want_map=True)
+    assert f32_hex(lv) == f32_hex(ov) and np.array_equal(lm.view(np.uint32), om.view(np.uint32))
+    cv, cm = ssim_amd.compute_ssim_channels(a, b, want_map=True)
+    assert [f32_hex(x) for x in cv] == [f32_hex(x) for x in want]
+    # bottom-up interleaved input addresses the same pixels
+    import ctypes
+    lib = ssim_amd.load_library()
+    af, bf = np.ascontiguousarray(a[::-1]), np.ascontiguousarray(b[::-1])
+    out3 = (ctypes.c_float * 3)()
+    rc = lib.rmgr_ssim_hip_compute_ssim_channels_host(None, out3, af.ctypes.data + (h - 1) * w * 3, -w * 3, bf.ctypes.data + (h - 1) * w * 3, -w * 3, w, h, 3, None)
+    assert rc == 0 and [f32_hex(x) for x in out3] == [f32_hex(x) for x in want]
+    one = ctypes.c_float()
+    rc = lib.rmgr_ssim_hip_compute_ssim_luminance_host(None, ctypes.byref(one), af.ctypes.data + (h - 1) * w * 3, -w * 3, bf.ctypes.data + (h - 1) * w * 3, -w * 3, w, h, 3, None)
+    assert rc == 0 and f32_hex(one.value) == f32_hex(ov)
