@@ -7,8 +7,9 @@
 //
 // Design (DESIGN.md has the long form):
 //  * Work unit = one 64-lane wavefront = one workgroup = one vertical STRIP of the image:
-//    64*C adjacent output columns (C = columns per lane) x strip_rows output rows.  No
-//    inter-wave communication, hence no real barriers; thousands of strips fill 256 CUs.
+//    128 (two per lane; ssim_strip2_kernel) or 64 (ssim_strip1_kernel) adjacent output columns x
+//    strip_rows output rows.  No inter-wave communication, hence no real barriers; thousands of
+//    strips fill 256 CUs.
 //  * The strip walks DOWN its rows.  Per source row the wave (a) loads the row's uint8 pixels
 //    of A and B (edge-clamped, any step/stride) one row ahead into registers, (b) converts them
 //    and writes the five statistic planes a, b, a^2, b^2, ab of that row into a 2-slot LDS ring
@@ -191,65 +192,88 @@ struct KArgs {
     double          gd[6];        // separable taps, fp64
 };
 
-// LDS row slot: the five statistic planes of one source row, PAD pixels of halo each side
-// (5 needed; 8 keeps every wide read naturally aligned).
-template <int C>
-struct RowSlot {
-    static constexpr int STRIP_W = 64 * C;
-    static constexpr int PAD = 8;
-    static constexpr int ROW_PX = STRIP_W + 2 * PAD;
-    f2    ab[ROW_PX];   // (a, b)
-    f2    q[ROW_PX];    // (a*a, b*b)
-    float x[ROW_PX];    // a*b
+// What every strip kernel does first: find its strip and its image pair.
+struct Strip {
+    PairDesc pd;                 // wave-uniform (SGPRs)
+    int64_t  W, H, x0, y0, y_end;
+    uint32_t sx, sy;
 };
 
-// ---------------------------------------------------------------------------------------------
-// The strip kernel.  MODE: arithmetic; C: columns per lane; MAP: write the per-pixel map.
-// ---------------------------------------------------------------------------------------------
-template <int MODE, int C, bool MAP>
-__global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
+__device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
 {
-    typedef RowSlot<C> Slot;
-    constexpr int STRIP_W = Slot::STRIP_W, PAD = Slot::PAD, ROW_PX = Slot::ROW_PX;
-    constexpr int NLOAD = (ROW_PX + 63) / 64;  // pixels each lane stages per row (2 or 3)
-    constexpr bool DBL = (MODE == MODE_DOUBLE);
-    constexpr bool FUSED = (MODE != MODE_UNFUSED);
-    static_assert(!DBL || C == 1, "fp64 mode runs one column per lane");
-    typedef typename std::conditional<DBL, d2, f2>::type PV;                                     // plane-pair streams
-    typedef typename std::conditional<DBL, double, typename std::conditional<C == 2, f2, float>::type>::type XV;  // ab stream
-
-    __shared__ __attribute__((aligned(16))) Slot ring[2];
-
-    const int lane = threadIdx.x;
-
+    Strip st;
     // XCD-aware strip order.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round
     // robin; left to itself that puts horizontally adjacent strips -- which share their 2 x 8 halo
-    // columns and hence cache lines -- on different L2s.  Give each XCD a contiguous run of
-    // (strip_x, strip_y) instead (speed only; correctness does not depend on placement).
-    uint32_t sx = blockIdx.x, sy = blockIdx.y;
-    {
-        const uint32_t per_img = args.strips_x * args.strips_y;
-        if ((per_img & 7u) == 0) {
-            const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
-            const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
-            sy = swz / args.strips_x;
-            sx = swz - sy * args.strips_x;
-        }
+    // columns and hence cache lines -- on different L2s (measured: 3.07x the algorithmic HBM reads).
+    // Give each XCD a contiguous run of (strip_x, strip_y) instead: 1.07x.  Speed only; correctness
+    // does not depend on placement.
+    st.sx = blockIdx.x; st.sy = blockIdx.y;
+    const uint32_t per_img = args.strips_x * args.strips_y;
+    if ((per_img & 7u) == 0) {
+        const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
+        const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
+        st.sy = swz / args.strips_x;
+        st.sx = swz - st.sy * args.strips_x;
     }
-
     // Everything in the descriptor is wave-uniform: keep it in SGPRs so that row addressing is
     // scalar arithmetic (a descriptor fetched through a pointer would otherwise sit in VGPRs).
-    PairDesc pd = args.single;
+    st.pd = args.single;
     if (args.descs) {
         const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
-        pd.a = (const uint8_t*)uniform64((int64_t)gd->a); pd.a_step = uniform64(gd->a_step); pd.a_stride = uniform64(gd->a_stride);
-        pd.b = (const uint8_t*)uniform64((int64_t)gd->b); pd.b_step = uniform64(gd->b_step); pd.b_stride = uniform64(gd->b_stride);
-        pd.map = (float*)uniform64((int64_t)gd->map); pd.map_step = uniform64(gd->map_step); pd.map_stride = uniform64(gd->map_stride);
+        st.pd.a = (const uint8_t*)uniform64((int64_t)gd->a); st.pd.a_step = uniform64(gd->a_step); st.pd.a_stride = uniform64(gd->a_stride);
+        st.pd.b = (const uint8_t*)uniform64((int64_t)gd->b); st.pd.b_step = uniform64(gd->b_step); st.pd.b_stride = uniform64(gd->b_stride);
+        st.pd.map = (float*)uniform64((int64_t)gd->map); st.pd.map_step = uniform64(gd->map_step); st.pd.map_stride = uniform64(gd->map_stride);
     }
-    const int64_t W = args.width, H = args.height;
-    const int64_t x0 = (int64_t)sx * STRIP_W;
-    const int64_t y0 = (int64_t)sy * args.strip_rows;
-    const int64_t y_end = (y0 + args.strip_rows < H) ? y0 + args.strip_rows : H;
+    st.W = args.width; st.H = args.height;
+    st.x0 = (int64_t)st.sx * strip_w;
+    st.y0 = (int64_t)st.sy * args.strip_rows;
+    st.y_end = (st.y0 + args.strip_rows < st.H) ? st.y0 + args.strip_rows : st.H;
+    return st;
+}
+
+// Strip total: lanes in a fixed butterfly order -> one fp64 partial per strip.
+__device__ __forceinline__ void strip_finish(const KArgs& args, const Strip& st, double tot)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        tot += __shfl_down(tot, off, 64);
+    if (threadIdx.x == 0)
+        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + st.sy) * args.strips_x + st.sx] = tot;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ssim_strip2_kernel -- the default kernel of the fp32 modes: two adjacent columns per lane,
+// 128-column strips.  LDS slot = one source row with 8 px of halo each side (5 needed; 8 keeps
+// every wide read naturally aligned): (a,b) pairs, (a*a,b*b) pairs, and the ab plane stored as
+// pairs xx[p] = (ab[p], ab[p+1]) so that ALL five blur streams are packed-fp32 code on naturally
+// aligned register pairs (no v_pk_mov shuffles), fed by 16-byte ds_read_b128.
+// Tried and dropped (measured on MI355X, round 1): refilling each plane's window for row r+1 right
+// after its last use (+36 VGPRs -> 1 wave/SIMD), unrolling the row loop over the two LDS slots
+// (312 registers), skipping the row sums halo rows cannot use (branches in the hot loop: -10 %),
+// forcing 3 waves/SIMD with launch bounds (spills: 5x slower).
+// ---------------------------------------------------------------------------------------------
+struct Slot2 {
+    static constexpr int STRIP_W = 128, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
+    f2 ab[ROW_PX];   // (a, b)
+    f2 q[ROW_PX];    // (a*a, b*b)
+    f2 xx[ROW_PX];   // (ab[p], ab[p+1])
+};
+
+template <int MODE, bool MAP>
+__global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
+{
+    constexpr int PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
+    constexpr int NLOAD = 3;                         // pixels each lane stages per row
+    constexpr bool FUSED = (MODE != MODE_UNFUSED);
+    constexpr bool EXACT = (MODE == MODE_EXACT || MODE == MODE_UNFUSED);
+    static_assert(MODE != MODE_DOUBLE, "fp64 mode uses ssim_strip1_kernel");
+
+    __shared__ __attribute__((aligned(16))) Slot2 ring[2];
+
+    const int lane = threadIdx.x;
+    const Strip st = strip_setup(args, Slot2::STRIP_W);
+    const PairDesc& pd = st.pd;
+    const int64_t W = st.W, H = st.H, x0 = st.x0, y0 = st.y0, y_end = st.y_end;
 
     // Per-lane staging columns: pixel p of the slot is image column clamp(x0 - PAD + p)
     // (edge replication of the IMAGE, src/ssim.cpp:529-554).
@@ -277,218 +301,133 @@ __global__ __launch_bounds__(64) void ssim_strip_kernel(const KArgs args)
             vb[t] = rb[offB[t]];
         }
     };
-    auto stage = [&](Slot& s) {    // registers -> the five planes of one LDS slot
+    auto stage = [&](Slot2& s) {    // registers -> the five planes of one LDS slot
+        float* xf = reinterpret_cast<float*>(s.xx);
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
             const float a = (float)va[t], b = (float)vb[t];   // retrieve_tile: uint8 -> Float
             const f2 ab = {a, b};
-            s.ab[sp[t]] = ab;
-            s.q[sp[t]] = ab * ab;                              // multiply: a*a, b*b (exact)
-            s.x[sp[t]] = a * b;                                //           a*b
+            const float x = a * b;                            // multiply (exact for 8-bit inputs)
+            const int p = sp[t];
+            s.ab[p] = ab;
+            s.q[p] = ab * ab;
+            xf[2 * p] = x;                          // xx[p].lo
+            xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
         }
     };
 
     // Accumulator rings (zero == the memset of src/ssim_fma.cpp:187).
-    PV accAB[C][11], accQ[C][11];
-    XV accX[11];
+    f2 accAB[2][11], accQ[2][11], accX[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            accAB[c][k] = VT<PV>::splat(0);
-            accQ[c][k] = VT<PV>::splat(0);
-        }
-        accX[k] = VT<XV>::splat(0);
+        accAB[0][k] = accAB[1][k] = accQ[0][k] = accQ[1][k] = accX[k] = f2{0.0f, 0.0f};
     }
-
-    double colsum[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) colsum[c] = 0.0;
+    double colsum = 0.0;
 
     const int64_t r_begin = y0 - 5, r_end = y_end + 5;
     fetch(r_begin);
     stage(ring[0]);
     fetch(r_begin + 1);
-    int cur = 0;
+    stage(ring[1]);
+    fetch(r_begin + 2);
+    __syncthreads();
 
+    int cur = 0;
 #pragma unroll 1
     for (int64_t r = r_begin; r < r_end; ++r) {
-        // Software pipeline: row r+1 goes to the other slot, row r+2 is requested from memory,
-        // then row r is consumed.  One wave == one workgroup: the barrier only orders LDS.
-        stage(ring[cur ^ 1]);
-        fetch(r + 2);
-        __syncthreads();
-        const Slot& s = ring[cur];
+        // One wave == one workgroup: the barriers only order LDS (they compile to nothing).
+        const Slot2& s = ring[cur];
 
-        // ---- window reads: this lane's C columns sit at slot pixels C*lane+PAD .. +C-1 ----
-        constexpr int WN = (C == 2) ? 14 : 11;            // pixels read per plane
-        constexpr int CTR = (C == 2) ? 6 : 5;             // index of column 0's centre
-        f2 wab[WN], wq[WN];
-        float wx[WN];
-        if constexpr (C == 2) {
-            const int base = 2 * lane + PAD - 6;           // even -> 16-byte aligned f4 reads
+        // ---- window reads: this lane's two columns sit at slot pixels 2*lane+8, +9 ----
+        f2 wab[14], wq[14], wxx[12];
+        const int e = 2 * lane + PAD - 6;               // even: every read below is 16-byte aligned
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const f4 v = *reinterpret_cast<const f4*>(&s.ab[base + 2 * t]);
-                const f4 u = *reinterpret_cast<const f4*>(&s.q[base + 2 * t]);
-                const f2 z = *reinterpret_cast<const f2*>(&s.x[base + 2 * t]);
-                wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
-                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-                wx[2 * t] = z.x;   wx[2 * t + 1] = z.y;
-            }
-        } else {
-            const int base = lane + PAD - 5;
+        for (int t = 0; t < 7; ++t) {
+            const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
+            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+            wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
+            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+        }
 #pragma unroll
-            for (int t = 0; t < 11; ++t) {
-                wab[t] = s.ab[base + t];
-                wq[t] = s.q[base + t];
-                wx[t] = s.x[base + t];
-            }
+        for (int t = 0; t < 6; ++t) {
+            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
         }
 
         // ---- blur: fold s[x+i]+s[x-i] (src/ssim_fma.cpp:196-201), then the row scatter ----
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int m = CTR + c;
+        for (int c = 0; c < 2; ++c) {
+            const int m = 6 + c;
             const f2 a1 = wab[m + 1] + wab[m - 1], a2 = wab[m + 2] + wab[m - 2], a3 = wab[m + 3] + wab[m - 3],
                      a4 = wab[m + 4] + wab[m - 4], a5 = wab[m + 5] + wab[m - 5];
             const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
                      q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
-            if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
+            if constexpr (EXACT) {
                 blur_exact<FUSED>(accAB[c], wab[m], a1, a2, a3, a4, a5);
                 blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
-            } else if constexpr (MODE == MODE_FAST) {
+            } else {
                 blur_separable(accAB[c], wab[m], a1, a2, a3, a4, a5, args.gf);
                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
-            } else {
-                blur_separable(accAB[c], to_f64(wab[m]), to_f64(a1), to_f64(a2), to_f64(a3), to_f64(a4), to_f64(a5), args.gd);
-                blur_separable(accQ[c], to_f64(wq[m]), to_f64(q1), to_f64(q2), to_f64(q3), to_f64(q4), to_f64(q5), args.gd);
             }
         }
-        {
-            typedef typename std::conditional<C == 2, f2, float>::type XS;  // fp32 folded sums of the ab plane
-            XS x0v, x1, x2, x3, x4, x5;
-            if constexpr (C == 2) {
-                x0v = f2{wx[CTR], wx[CTR + 1]};
-                x1 = f2{wx[CTR + 1] + wx[CTR - 1], wx[CTR + 2] + wx[CTR]};
-                x2 = f2{wx[CTR + 2] + wx[CTR - 2], wx[CTR + 3] + wx[CTR - 1]};
-                x3 = f2{wx[CTR + 3] + wx[CTR - 3], wx[CTR + 4] + wx[CTR - 2]};
-                x4 = f2{wx[CTR + 4] + wx[CTR - 4], wx[CTR + 5] + wx[CTR - 3]};
-                x5 = f2{wx[CTR + 5] + wx[CTR - 5], wx[CTR + 6] + wx[CTR - 4]};
-            } else {
-                x0v = wx[CTR];
-                x1 = wx[CTR + 1] + wx[CTR - 1];
-                x2 = wx[CTR + 2] + wx[CTR - 2];
-                x3 = wx[CTR + 3] + wx[CTR - 3];
-                x4 = wx[CTR + 4] + wx[CTR - 4];
-                x5 = wx[CTR + 5] + wx[CTR - 5];
-            }
-            if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED)
-                blur_exact<FUSED>(accX, x0v, x1, x2, x3, x4, x5);
-            else if constexpr (MODE == MODE_FAST)
-                blur_separable(accX, x0v, x1, x2, x3, x4, x5, args.gf);
-            else
-                blur_separable(accX, to_f64(x0v), to_f64(x1), to_f64(x2), to_f64(x3), to_f64(x4), to_f64(x5), args.gd);
+        {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
+            const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
+            if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
+            else                 blur_separable(accX, wxx[6], x1, x2, x3, x4, x5, args.gf);
         }
 
         // ---- ring entry 0 is now the finished output row y = r - 5 (sum_tile) ----
         const int64_t y = r - 5;
         if (y >= y0) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int64_t x = x0 + (int64_t)C * lane + c;
+            for (int c = 0; c < 2; ++c) {
+                const int64_t x = x0 + 2 * lane + c;
                 if (x < W) {
-                    float vmap;
-                    if constexpr (DBL) {
-                        const double v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, accX[0], args.c1d, args.c2d);
-                        colsum[c] += v;
-                        vmap = (float)v;
-                    } else {
-                        float eab;
-                        if constexpr (C == 2) eab = (c == 0) ? accX[0].x : accX[0].y;
-                        else                  eab = accX[0];
-                        const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, eab, args.c1, args.c2);
-                        colsum[c] += (double)v;   // fp64 accumulation, src/ssim_avx.cpp:357-358
-                        vmap = v;
-                    }
+                    const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
+                    colsum += (double)v;            // fp64 accumulation, src/ssim_avx.cpp:357-358
                     if constexpr (MAP)
-                        ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = vmap;
+                        ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
                 }
             }
         }
         __syncthreads();
+        stage(ring[cur]);                           // row r+2 replaces row r
+        fetch(r + 3);
+        __syncthreads();
         cur ^= 1;
     }
-
-    // Strip total: lanes in a fixed butterfly order -> one fp64 partial per strip.
-    double tot = colsum[0];
-#pragma unroll
-    for (int c = 1; c < C; ++c) tot += colsum[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        tot += __shfl_down(tot, off, 64);
-    if (lane == 0)
-        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + sy) * args.strips_x + sx] = tot;
+    strip_finish(args, st, colsum);
 }
 
 // ---------------------------------------------------------------------------------------------
-// ssim_strip2_kernel: the tuned two-columns-per-lane kernel (fp32 modes).  Same arithmetic as
-// ssim_strip_kernel<MODE, 2, MAP>, restructured for VALU efficiency:
-//  * the ab plane is staged as pairs xx[p] = (ab[p], ab[p+1]) so that its folds are packed adds on
-//    naturally aligned register pairs like the two plane-pair streams (no v_pk_mov shuffles);
-//  * staging of row r+2 and the fetch of row r+3 sit behind the epilogue instead of in front of the blur.
-// Tried and dropped (measured on MI355X, round 1): refilling each plane's window for row r+1 right
-// after its last use (+36 VGPRs -> 1 wave/SIMD), unrolling the row loop over the two LDS slots
-// (312 registers), skipping the row sums halo rows cannot use (branches in the hot loop: -10 %).
+// ssim_strip1_kernel -- one column per lane, 64-column strips.  Half the accumulator registers
+// (4 waves/SIMD in fp32), more loader/LDS work per pixel: measured 10-14 % slower than the
+// two-column kernel in the fp32 modes (kept as tuning variant 1), and the only shape whose fp64
+// accumulators (110 VGPRs) fit: MODE_DOUBLE always runs here.  The ab plane is a scalar stream.
 // ---------------------------------------------------------------------------------------------
-#ifndef SSIM2_REFILL
-#define SSIM2_REFILL 0   // refilling each plane's window right after its last use costs ~36 VGPRs (drops to 1 wave/SIMD)
-#endif
-
-struct Slot2 {
-    static constexpr int STRIP_W = 128, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
-    f2 ab[ROW_PX];   // (a, b)
-    f2 q[ROW_PX];    // (a*a, b*b)
-    f2 xx[ROW_PX];   // (ab[p], ab[p+1])
-};
-
-struct Window2 {
-    f2 ab[14], q[14], xx[12];
+struct Slot1 {
+    static constexpr int STRIP_W = 64, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
+    f2    ab[ROW_PX];   // (a, b)
+    f2    q[ROW_PX];    // (a*a, b*b)
+    float x[ROW_PX];    // a*b
 };
 
 template <int MODE, bool MAP>
-__global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
+__global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
 {
-    constexpr int STRIP_W = Slot2::STRIP_W, PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
-    constexpr int NLOAD = 3;
+    constexpr int PAD = Slot1::PAD, ROW_PX = Slot1::ROW_PX;
+    constexpr int NLOAD = 2;
+    constexpr bool DBL = (MODE == MODE_DOUBLE);
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
-    constexpr bool EXACT = (MODE == MODE_EXACT || MODE == MODE_UNFUSED);
-    static_assert(MODE != MODE_DOUBLE, "fp64 mode uses ssim_strip_kernel");
+    typedef typename std::conditional<DBL, d2, f2>::type PV;         // plane-pair streams
+    typedef typename std::conditional<DBL, double, float>::type XV;  // ab stream
 
-    __shared__ __attribute__((aligned(16))) Slot2 ring[2];
+    __shared__ __attribute__((aligned(16))) Slot1 ring[2];
 
     const int lane = threadIdx.x;
-    uint32_t sx = blockIdx.x, sy = blockIdx.y;
-    {   // XCD-aware strip order (see ssim_strip_kernel)
-        const uint32_t per_img = args.strips_x * args.strips_y;
-        if ((per_img & 7u) == 0) {
-            const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
-            const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
-            sy = swz / args.strips_x;
-            sx = swz - sy * args.strips_x;
-        }
-    }
-    PairDesc pd = args.single;
-    if (args.descs) {
-        const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
-        pd.a = (const uint8_t*)uniform64((int64_t)gd->a); pd.a_step = uniform64(gd->a_step); pd.a_stride = uniform64(gd->a_stride);
-        pd.b = (const uint8_t*)uniform64((int64_t)gd->b); pd.b_step = uniform64(gd->b_step); pd.b_stride = uniform64(gd->b_stride);
-        pd.map = (float*)uniform64((int64_t)gd->map); pd.map_step = uniform64(gd->map_step); pd.map_stride = uniform64(gd->map_stride);
-    }
-    const int64_t W = args.width, H = args.height;
-    const int64_t x0 = (int64_t)sx * STRIP_W;
-    const int64_t y0 = (int64_t)sy * args.strip_rows;
-    const int64_t y_end = (y0 + args.strip_rows < H) ? y0 + args.strip_rows : H;
+    const Strip st = strip_setup(args, Slot1::STRIP_W);
+    const PairDesc& pd = st.pd;
+    const int64_t W = st.W, H = st.H, x0 = st.x0, y0 = st.y0, y_end = st.y_end;
 
     int     sp[NLOAD];
     int64_t offA[NLOAD], offB[NLOAD];
@@ -514,132 +453,89 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             vb[t] = rb[offB[t]];
         }
     };
-    auto stage = [&](Slot2& s) {
-        float* xf = reinterpret_cast<float*>(s.xx);
+    auto stage = [&](Slot1& s) {
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
             const float a = (float)va[t], b = (float)vb[t];
             const f2 ab = {a, b};
-            const float x = a * b;
-            const int p = sp[t];
-            s.ab[p] = ab;
-            s.q[p] = ab * ab;
-            xf[2 * p] = x;                          // xx[p].lo
-            xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
-        }
-    };
-    // Window reads, one plane at a time: this lane's two columns sit at slot pixels 2*lane+8, +9.
-    const int e = 2 * lane + PAD - 6;               // even: every read below is 16-byte aligned
-    auto load_ab = [&](const Slot2& s, Window2& w) {
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
-            w.ab[2 * t] = v.xy; w.ab[2 * t + 1] = v.zw;
-        }
-    };
-    auto load_q = [&](const Slot2& s, Window2& w) {
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-            w.q[2 * t] = u.xy;  w.q[2 * t + 1] = u.zw;
-        }
-    };
-    auto load_xx = [&](const Slot2& s, Window2& w) {
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-            w.xx[2 * t] = z.xy; w.xx[2 * t + 1] = z.zw;
+            s.ab[sp[t]] = ab;
+            s.q[sp[t]] = ab * ab;
+            s.x[sp[t]] = a * b;
         }
     };
 
-    f2 accAB[2][11], accQ[2][11], accX[11];
+    PV accAB[11], accQ[11];
+    XV accX[11];
 #pragma unroll
     for (int k = 0; k < 11; ++k) {
-        accAB[0][k] = accAB[1][k] = accQ[0][k] = accQ[1][k] = accX[k] = f2{0.0f, 0.0f};
+        accAB[k] = VT<PV>::splat(0);
+        accQ[k] = VT<PV>::splat(0);
+        accX[k] = VT<XV>::splat(0);
     }
     double colsum = 0.0;
 
-    // One source row: each plane's window is consumed (both columns), then immediately refilled
-    // from the OTHER slot with the next row's pixels, so the LDS latency of row r+1 hides behind
-    // the remaining streams of row r, the epilogue and the staging -- without extra registers.
-    auto blur_row = [&](Window2& w, const Slot2& next) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int m = 6 + c;
-            const f2 a1 = w.ab[m + 1] + w.ab[m - 1], a2 = w.ab[m + 2] + w.ab[m - 2], a3 = w.ab[m + 3] + w.ab[m - 3],
-                     a4 = w.ab[m + 4] + w.ab[m - 4], a5 = w.ab[m + 5] + w.ab[m - 5];
-            if constexpr (EXACT) {
-                blur_exact<FUSED>(accAB[c], w.ab[m], a1, a2, a3, a4, a5);
-            } else {
-                blur_separable(accAB[c], w.ab[m], a1, a2, a3, a4, a5, args.gf);
-            }
-        }
-        if (SSIM2_REFILL) load_ab(next, w);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int m = 6 + c;
-            const f2 q1 = w.q[m + 1] + w.q[m - 1], q2 = w.q[m + 2] + w.q[m - 2], q3 = w.q[m + 3] + w.q[m - 3],
-                     q4 = w.q[m + 4] + w.q[m - 4], q5 = w.q[m + 5] + w.q[m - 5];
-            if constexpr (EXACT) {
-                blur_exact<FUSED>(accQ[c], w.q[m], q1, q2, q3, q4, q5);
-            } else {
-                blur_separable(accQ[c], w.q[m], q1, q2, q3, q4, q5, args.gf);
-            }
-        }
-        if (SSIM2_REFILL) load_q(next, w);
-        // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); centre pair is index 6
-        const f2 x1 = w.xx[7] + w.xx[5], x2 = w.xx[8] + w.xx[4], x3 = w.xx[9] + w.xx[3], x4 = w.xx[10] + w.xx[2], x5 = w.xx[11] + w.xx[1];
-        if constexpr (EXACT) {
-            blur_exact<FUSED>(accX, w.xx[6], x1, x2, x3, x4, x5);
-        } else {
-            blur_separable(accX, w.xx[6], x1, x2, x3, x4, x5, args.gf);
-        }
-        if (SSIM2_REFILL) load_xx(next, w);
-    };
-    auto epilogue = [&](int64_t y) {    // ring entry 0 = finished output row y (sum_tile)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int64_t x = x0 + 2 * lane + c;
-            if (x < W) {
-                const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
-                colsum += (double)v;
-                if constexpr (MAP)
-                    ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
-            }
-        }
-    };
     const int64_t r_begin = y0 - 5, r_end = y_end + 5;
     fetch(r_begin);
     stage(ring[0]);
     fetch(r_begin + 1);
-    stage(ring[1]);
-    fetch(r_begin + 2);
-    __syncthreads();
-    Window2 w;
-    load_ab(ring[0], w);
-    load_q(ring[0], w);
-    load_xx(ring[0], w);
-
     int cur = 0;
+
 #pragma unroll 1
-    for (int64_t r = r_begin; r < r_end; r += 1) {
-        // ---- even half: w holds row r (from ring[0]); row r+1 is staged in ring[1] ----
-        if (!SSIM2_REFILL) { load_ab(ring[cur], w); load_q(ring[cur], w); load_xx(ring[cur], w); }
-        blur_row(w, ring[cur ^ 1]);
-        if (r - 5 >= y0) epilogue(r - 5);
-        stage(ring[cur]);
-        fetch(r + 3);
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        // Software pipeline: row r+1 goes to the other slot, row r+2 is requested from memory,
+        // then row r is consumed.
+        stage(ring[cur ^ 1]);
+        fetch(r + 2);
         __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);          // keep the two halves' windows from overlapping in registers
+        const Slot1& s = ring[cur];
+
+        f2 wab[11], wq[11];
+        float wx[11];
+        const int base = lane + PAD - 5;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+            wab[t] = s.ab[base + t];
+            wq[t] = s.q[base + t];
+            wx[t] = s.x[base + t];
+        }
+        const f2 a1 = wab[6] + wab[4], a2 = wab[7] + wab[3], a3 = wab[8] + wab[2], a4 = wab[9] + wab[1], a5 = wab[10] + wab[0];
+        const f2 q1 = wq[6] + wq[4], q2 = wq[7] + wq[3], q3 = wq[8] + wq[2], q4 = wq[9] + wq[1], q5 = wq[10] + wq[0];
+        const float x1 = wx[6] + wx[4], x2 = wx[7] + wx[3], x3 = wx[8] + wx[2], x4 = wx[9] + wx[1], x5 = wx[10] + wx[0];
+        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
+            blur_exact<FUSED>(accAB, wab[5], a1, a2, a3, a4, a5);
+            blur_exact<FUSED>(accQ, wq[5], q1, q2, q3, q4, q5);
+            blur_exact<FUSED>(accX, wx[5], x1, x2, x3, x4, x5);
+        } else if constexpr (MODE == MODE_FAST) {
+            blur_separable(accAB, wab[5], a1, a2, a3, a4, a5, args.gf);
+            blur_separable(accQ, wq[5], q1, q2, q3, q4, q5, args.gf);
+            blur_separable(accX, wx[5], x1, x2, x3, x4, x5, args.gf);
+        } else {
+            // fp64 internals: the folded sums are exact integers in fp32; everything after is double
+            blur_separable(accAB, to_f64(wab[5]), to_f64(a1), to_f64(a2), to_f64(a3), to_f64(a4), to_f64(a5), args.gd);
+            blur_separable(accQ, to_f64(wq[5]), to_f64(q1), to_f64(q2), to_f64(q3), to_f64(q4), to_f64(q5), args.gd);
+            blur_separable(accX, to_f64(wx[5]), to_f64(x1), to_f64(x2), to_f64(x3), to_f64(x4), to_f64(x5), args.gd);
+        }
+
+        const int64_t y = r - 5;
+        const int64_t x = x0 + lane;
+        if (y >= y0 && x < W) {
+            float vmap;
+            if constexpr (DBL) {
+                const double v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1d, args.c2d);
+                colsum += v;
+                vmap = (float)v;                    // the reference's map is float in the double build too
+            } else {
+                const float v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1, args.c2);
+                colsum += (double)v;
+                vmap = v;
+            }
+            if constexpr (MAP)
+                ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = vmap;
+        }
+        __syncthreads();
         cur ^= 1;
     }
-
-    double tot = colsum;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        tot += __shfl_down(tot, off, 64);
-    if (lane == 0)
-        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + sy) * args.strips_x + sx] = tot;
+    strip_finish(args, st, colsum);
 }
 
 // Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then
@@ -663,21 +559,21 @@ __global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restri
         sums[blockIdx.x] = sh[0];
 }
 
-template <int MODE, int C>
-hipError_t launch_mode(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
-{
-    const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
-    if (map) hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, true>), grid, block, 0, stream, ka);
-    else     hipLaunchKernelGGL((ssim_strip_kernel<MODE, C, false>), grid, block, 0, stream, ka);
-    return hipGetLastError();
-}
-
 template <int MODE>
 hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
     if (map) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, true>), grid, block, 0, stream, ka);
     else     hipLaunchKernelGGL((ssim_strip2_kernel<MODE, false>), grid, block, 0, stream, ka);
+    return hipGetLastError();
+}
+
+template <int MODE>
+hipError_t launch_strip1(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
+{
+    const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
+    if (map) hipLaunchKernelGGL((ssim_strip1_kernel<MODE, true>), grid, block, 0, stream, ka);
+    else     hipLaunchKernelGGL((ssim_strip1_kernel<MODE, false>), grid, block, 0, stream, ka);
     return hipGetLastError();
 }
 
@@ -802,22 +698,14 @@ hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* de
     }
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
     hipError_t err;
-    const int C = columns_per_lane(mode, variant);
-    // variant 0: library default (the two-column kernels: ssim_strip_kernel<.,2,.> for the bit-exact modes,
-    // ssim_strip2_kernel for MODE_FAST, where the paired ab plane measured +4 %); 1: one column per lane;
-    // 2: ssim_strip_kernel<.,2,.> for every mode; 3: ssim_strip2_kernel for every fp32 mode.
-    const bool use2 = (mode != MODE_DOUBLE) && (variant == 3 || (variant == 0 && mode == MODE_FAST));
-    if (use2) {
-        switch (mode) {
-        case MODE_EXACT:   err = launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
-        case MODE_UNFUSED: err = launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
-        default:           err = launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
-        }
-    } else switch (mode) {
-    case MODE_EXACT:   err = (C == 2) ? launch_mode<MODE_EXACT, 2>(geo, ka, map, stream)   : launch_mode<MODE_EXACT, 1>(geo, ka, map, stream);   break;
-    case MODE_UNFUSED: err = (C == 2) ? launch_mode<MODE_UNFUSED, 2>(geo, ka, map, stream) : launch_mode<MODE_UNFUSED, 1>(geo, ka, map, stream); break;
-    case MODE_FAST:    err = (C == 2) ? launch_mode<MODE_FAST, 2>(geo, ka, map, stream)    : launch_mode<MODE_FAST, 1>(geo, ka, map, stream);    break;
-    case MODE_DOUBLE:  err = launch_mode<MODE_DOUBLE, 1>(geo, ka, map, stream); break;
+    // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel).
+    // MODE_DOUBLE always runs one column per lane.
+    const bool one = columns_per_lane(mode, variant) == 1;
+    switch (mode) {
+    case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
+    case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
+    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
+    case MODE_DOUBLE:  err = launch_strip1<MODE_DOUBLE>(geo, ka, map, stream); break;
     default:           return hipErrorInvalidValue;
     }
     if (err != hipSuccess) return err;

@@ -33,7 +33,7 @@ def test_extension_is_loaded_and_device_is_gfx950(gpu_ctx):
     assert "gfx950" in d, d
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1])
 def test_golden_fixtures_exact_mode(gpu_ctx, manifest, variant):
     gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
     gpu_ctx.set_tuning(0, variant)
@@ -81,7 +81,7 @@ SIZES = [(1, 1), (1, 37), (37, 1), (3, 200), (200, 3), (10, 10), (11, 11), (63, 
          (129, 128), (127, 129), (130, 600), (300, 301)]
 
 
-@pytest.mark.parametrize("variant,strip_rows", [(0, 0), (0, 7), (0, 64), (1, 0), (1, 33), (3, 0), (3, 5)])
+@pytest.mark.parametrize("variant,strip_rows", [(0, 0), (0, 7), (0, 64), (0, 5), (1, 0), (1, 33)])
 def test_random_and_ragged_sizes_vs_oracle(gpu_ctx, oracle, variant, strip_rows):
     gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
     gpu_ctx.set_tuning(strip_rows, variant)
@@ -302,7 +302,7 @@ def test_full_size_known_answers_and_properties(gpu_ctx, oracle, manifest):
         pm = ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, db.ptr, 1, 4096, dm.ptr, 1, 4096)
         gpu_ctx.compute_device(pm)
         base = dm.download(np.float32, (4096, 4096))
-        for rows, variant in ((32, 0), (100, 0), (0, 1), (0, 3), (77, 3)):
+        for rows, variant in ((32, 0), (100, 0), (77, 0), (0, 1)):
             gpu_ctx.set_tuning(rows, variant)
             assert f32_hex(gpu_ctx.compute_device(pm)) == f32_hex(v)
             assert_same_map(dm.download(np.float32, (4096, 4096)), base, (rows, variant))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of kernel variants on one resident batch (within-process, several rounds).
 
-usage: python tools/ab.py [pairs=8] [size=4096] [mode=0] [rows=256] [variants=0,1,2] [rounds=5] [map=0]
+usage: python tools/ab.py [pairs=8] [size=4096] [mode=0] [rows=256] [variants=0,1] [rounds=5] [map=0]
 Set RMGR_SSIM_LIB=<path> to test an alternative build of the library in a separate run.
 """
 import os
@@ -20,7 +20,7 @@ from ssim_amd import synth  # noqa: E402
 def main():
     arg = lambda i, d: sys.argv[i] if len(sys.argv) > i else d
     pairs, size, mode, rows = int(arg(1, 8)), int(arg(2, 4096)), int(arg(3, 0)), int(arg(4, 256))
-    variants = [int(v) for v in arg(5, "0,1,2").split(",")]
+    variants = [int(v) for v in arg(5, "0,1").split(",")]
     rounds, want_map = int(arg(6, 5)), int(arg(7, 0))
     ctx = ssim_amd.Context(0, mode=mode)
     params = (ssim_amd.Params * pairs)()
