@@ -41,8 +41,20 @@ $(BIN)/rmgr-ssim: $(SRC)/ssim_cli.cpp $(OUT)/librmgr-ssim-hip.so include/rmgr/ss
 oracle:
 	$(MAKE) -C oracle all
 
+# Install layout of the reference (CMakeLists.txt:321-338): headers under include/rmgr, libraries under lib.
+# The reference's two link names (-lrmgr-ssim, -lrmgr-ssim-openmp) resolve to the one HIP library.
+PREFIX ?= /usr/local
+install: lib
+	install -d $(DESTDIR)$(PREFIX)/include/rmgr $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/bin $(DESTDIR)$(PREFIX)/lib/pkgconfig
+	install -m 644 include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-version.h include/rmgr/ssim-hip.h $(DESTDIR)$(PREFIX)/include/rmgr/
+	install -m 755 $(OUT)/librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/
+	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim.so
+	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim-openmp.so
+	install -m 755 $(BIN)/rmgr-ssim $(DESTDIR)$(PREFIX)/bin/
+	printf 'prefix=%s\nlibdir=$${prefix}/lib\nincludedir=$${prefix}/include\n\nName: rmgr-ssim\nDescription: SSIM (rmgr::ssim API) on AMD MI355X / gfx950\nVersion: 2.1.0\nLibs: -L$${libdir} -lrmgr-ssim-hip\nCflags: -I$${includedir}\n' '$(PREFIX)' > $(DESTDIR)$(PREFIX)/lib/pkgconfig/rmgr-ssim.pc
+
 clean:
 	rm -rf build $(OUT) $(BIN)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean
+.PHONY: all lib oracle clean install

@@ -105,6 +105,23 @@ rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uin
                                             const rmgr_uint8_t* src, ptrdiff_t srcStep, ptrdiff_t srcStride,
                                             rmgr_uint32_t width, rmgr_uint32_t height) RMGR_NOEXCEPT;
 
+/*
+ * Multi-GPU exchange without any other runtime: one process per GPU, images sharded by rank (no image
+ * data crosses GPUs), every rank enqueues its shard into ITS slice of a zero-initialised device vector
+ * of per-image fp64 sums, then all ranks call comm_allreduce_sums on the whole vector: one RCCL
+ * all-reduce(sum, fp64) over xGMI.  Adding zeros is exact, so the result does not depend on the GPU
+ * count.  This is the GPU-era form of the reference's per-thread partials + final loop
+ * (src/ssim.cpp:902-926, :1094-1100).  librccl.so is loaded on first use; ENOSYS if it is absent.
+ *   rank 0: comm_get_unique_id(id); ship the 128 bytes to the other ranks by any means (file, socket, MPI)
+ *   all:    comm_init(ctx, id, rankCount, rank);  ...  comm_allreduce_sums(ctx, sumsDevice, count);
+ */
+#define RMGR_SSIM_HIP_COMM_ID_BYTES 128
+rmgr_int32_t rmgr_ssim_hip_comm_get_unique_id(unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES]) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_comm_init(rmgr_ssim_hip_Context* ctx, const unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES],
+                                     rmgr_int32_t rankCount, rmgr_int32_t rank) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context* ctx, double* sumsDevice, rmgr_uint32_t count) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
 /* Blocks until everything enqueued on the context's stream has finished. */
 rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 

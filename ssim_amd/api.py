@@ -63,6 +63,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
+    "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -113,6 +114,10 @@ def load_library(path=None):
         "rmgr_ssim_hip_compute_ssim_channels_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
         "rmgr_ssim_hip_compute_ssim_luminance_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
         "rmgr_ssim_hip_luminance_device": [vp, vp, c_pd, vp, c_pd, c_pd, u32, u32],
+        "rmgr_ssim_hip_comm_get_unique_id": [ctypes.c_char_p],
+        "rmgr_ssim_hip_comm_init": [vp, ctypes.c_char_p, i32, i32],
+        "rmgr_ssim_hip_comm_allreduce_sums": [vp, vp, u32],
+        "rmgr_ssim_hip_comm_destroy": [vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)
@@ -163,13 +168,17 @@ def finalize(sums, width, height):
     return out
 
 
-def compute_ssim(a, b, want_map=False, openmp=False, allocator=False):
-    """The drop-in entry point rmgr_ssim_compute_ssim() on two host uint8 planes (H x W numpy)."""
+def compute_ssim(a, b, want_map=False, openmp=False, allocator=False, out_map=None):
+    """The drop-in entry point rmgr_ssim_compute_ssim() on two host uint8 planes (H x W numpy).
+    out_map: reuse this H x W float32 array for the map (avoids first-touch page faults in timing loops)."""
     lib = load_library()
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     h, w = a.shape
-    m = np.empty((h, w), np.float32) if want_map else None
+    if out_map is not None:
+        assert out_map.shape == (h, w) and out_map.dtype == np.float32 and out_map.flags.c_contiguous
+        want_map = True
+    m = (out_map if out_map is not None else np.empty((h, w), np.float32)) if want_map else None
     p = make_params(w, h, a.ctypes.data, 1, a.strides[0], b.ctypes.data, 1, b.strides[0],
                     m.ctypes.data if want_map else None, 1, w)
     if allocator:
@@ -288,6 +297,19 @@ class Context(object):
 
     def enqueue_batch(self, params_array, count, sums_dev_ptr):
         _check("rmgr_ssim_hip_enqueue_batch", self.lib.rmgr_ssim_hip_enqueue_batch(self.handle, count, params_array, sums_dev_ptr))
+
+    # ---- native RCCL exchange (rmgr_ssim_hip_comm_*) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check("rmgr_ssim_hip_comm_get_unique_id", load_library().rmgr_ssim_hip_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank_count, rank):
+        _check("rmgr_ssim_hip_comm_init", self.lib.rmgr_ssim_hip_comm_init(self.handle, unique_id, rank_count, rank))
+
+    def comm_allreduce_sums(self, sums_dev_ptr, count):
+        _check("rmgr_ssim_hip_comm_allreduce_sums", self.lib.rmgr_ssim_hip_comm_allreduce_sums(self.handle, sums_dev_ptr, count))
 
     def set_profiling(self, on):
         _check("rmgr_ssim_hip_set_profiling", self.lib.rmgr_ssim_hip_set_profiling(self.handle, 1 if on else 0))

@@ -6,7 +6,10 @@
 // no gfx950 device is usable every entry point fails loudly with ENODEV.
 #include <rmgr/ssim-hip.h>
 #include "ssim_kernels.h"
+#include <rccl/rccl.h>      // types only: the library is dlopen()ed on first use, never linked
+#include <dlfcn.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +38,8 @@ struct rmgr_ssim_hip_Context_ {
     float*    stage_map;    size_t stage_map_cap;  // floats
     // pinned host scratch
     double*   h_sums;       size_t h_sums_cap;     // doubles
+    float*    h_map[2];     size_t h_map_cap[2];   // floats: bounce buffers for the map copy-back
+    hipEvent_t map_ev[2];
     PairDesc* h_descs;      size_t h_descs_cap;
     size_t    descs_live;   // entries of `descs` that mirror h_descs (0: nothing uploaded)
 
@@ -43,6 +48,8 @@ struct rmgr_ssim_hip_Context_ {
     std::vector<std::pair<hipEvent_t, hipEvent_t> > free_events;
     uint64_t prof_launches;
     double   prof_ms;
+
+    ncclComm_t comm;          // RCCL communicator (rmgr_ssim_hip_comm_*), NULL until comm_init
 
     char describe[256];
     std::mutex lock;
@@ -245,6 +252,9 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->h_sums = NULL; c->h_sums_cap = 0;
     c->h_descs = NULL; c->h_descs_cap = 0;
     c->descs_live = 0;
+    c->h_map[0] = c->h_map[1] = NULL; c->h_map_cap[0] = c->h_map_cap[1] = 0;
+    c->map_ev[0] = c->map_ev[1] = NULL;
+    c->comm = NULL;
     c->profiling = false;
     c->prof_launches = 0;
     c->prof_ms = 0.0;
@@ -264,6 +274,7 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     if (!c) return EINVAL;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)rmgr_ssim_hip_comm_destroy(c);
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
@@ -274,6 +285,7 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     if (c->stage_map) (void)hipFree(c->stage_map);
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_descs) (void)hipHostFree(c->h_descs);
+    for (int i = 0; i < 2; ++i) { if (c->h_map[i]) (void)hipHostFree(c->h_map[i]); if (c->map_ev[i]) (void)hipEventDestroy(c->map_ev[i]); }
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -370,19 +382,18 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     const uint32_t W = params->width, H = params->height;
 
     // The reference allocates its tile scratch through params->alloc exactly once and fails with
-    // ENOMEM when that returns NULL (src/ssim.cpp:1048-1052).  Here the user allocator provides the
-    // host-side bounce buffer of the map (and keeps the ENOMEM contract observable).
-    const bool scatter_map = params->ssimMap != NULL && W && H && !(params->ssimStep == 1 && params->ssimStride >= (ptrdiff_t)W);
+    // ENOMEM when that returns NULL (src/ssim.cpp:1048-1052).  The GPU path has no use for host
+    // scratch, but the contract is kept observable: one 64-byte allocation, released before returning.
     void* user_mem = NULL;
     if (params->alloc != NULL) {
-        const size_t bytes = scatter_map ? sizeof(float) * (size_t)W * H : 64;
-        user_mem = params->alloc(bytes, 64);
+        user_mem = params->alloc(64, 64);        // nothing else needs host scratch: staging is pinned memory owned by the context
         if (user_mem == NULL) return ENOMEM;
     }
     struct Release {
-        const rmgr_ssim_Params* p; void* m; std::vector<float> own;
+        const rmgr_ssim_Params* p; void* m;
         ~Release() { if (m && p->dealloc) p->dealloc(m); }
-    } rel = {params, user_mem, std::vector<float>()};
+    } rel = {params, user_mem};
+    (void)rel;
 
     rmgr_ssim_Params dev = *params;
     if (W && H) {
@@ -414,25 +425,33 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
 
     if (params->ssimMap && W && H) {
-        if (!scatter_map) {
-            HIP_TRY(hipMemcpy2DAsync(params->ssimMap, sizeof(float) * (size_t)params->ssimStride, c->stage_map, sizeof(float) * W,
-                                     sizeof(float) * W, H, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-        } else {
-            float* bounce = static_cast<float*>(user_mem);
-            if (!bounce) {
-                try { rel.own.resize((size_t)W * H); } catch (...) { return ENOMEM; }
-                bounce = rel.own.data();
+        // Map back to the caller's (pageable) buffer: D2H into two pinned bounce buffers in row
+        // chunks, the CPU scatters chunk k-1 into ssimStep/ssimStride layout while chunk k is in flight.
+        const size_t rowsPerChunk = std::max<size_t>(1, (size_t(8) << 20) / (sizeof(float) * W));
+        const size_t chunkFloats = rowsPerChunk * W;
+        if ((rc = grow_pinned(c->h_map[0], c->h_map_cap[0], chunkFloats))) return rc;
+        if ((rc = grow_pinned(c->h_map[1], c->h_map_cap[1], chunkFloats))) return rc;
+        for (int i = 0; i < 2; ++i)
+            if (!c->map_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->map_ev[i], hipEventDisableTiming));
+        const size_t chunks = (H + rowsPerChunk - 1) / rowsPerChunk;
+        for (size_t k = 0; k <= chunks; ++k) {
+            if (k < chunks) {
+                const size_t y0 = k * rowsPerChunk, rows = std::min(rowsPerChunk, (size_t)H - y0);
+                HIP_TRY(hipMemcpyAsync(c->h_map[k & 1], c->stage_map + y0 * W, sizeof(float) * rows * W, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipEventRecord(c->map_ev[k & 1], c->stream));
             }
-            HIP_TRY(hipMemcpyAsync(bounce, c->stage_map, sizeof(float) * (size_t)W * H, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            for (uint32_t y = 0; y < H; ++y) {
-                float* row = params->ssimMap + (ptrdiff_t)y * params->ssimStride;
-                const float* src = bounce + (size_t)y * W;
-                for (uint32_t x = 0; x < W; ++x)
-                    row[(ptrdiff_t)x * params->ssimStep] = src[x];
+            if (k > 0) {
+                const size_t j = k - 1, y0 = j * rowsPerChunk, rows = std::min(rowsPerChunk, (size_t)H - y0);
+                HIP_TRY(hipEventSynchronize(c->map_ev[j & 1]));
+                const float* src = c->h_map[j & 1];
+                for (size_t y = 0; y < rows; ++y, src += W) {
+                    float* row = params->ssimMap + (ptrdiff_t)(y0 + y) * params->ssimStride;
+                    if (params->ssimStep == 1) memcpy(row, src, sizeof(float) * W);
+                    else for (uint32_t x = 0; x < W; ++x) row[(ptrdiff_t)x * params->ssimStep] = src[x];
+                }
             }
         }
+        HIP_TRY(hipStreamSynchronize(c->stream));
     } else {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -566,6 +585,95 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (ssim) *ssim = mean_of(c->h_sums[0], width, height);
     return 0;
+}
+
+// ---- RCCL, loaded lazily so that single-GPU users carry no dependency on it ----
+namespace {
+
+struct Rccl {
+    void* handle;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+};
+
+Rccl* rccl()
+{
+    static Rccl api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        memset(&api, 0, sizeof(api));
+        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !api.handle; ++i)
+            api.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) return;
+        api.GetUniqueId  = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(api.handle, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>(dlsym(api.handle, "ncclCommInitRank"));
+        api.AllReduce    = reinterpret_cast<ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>(dlsym(api.handle, "ncclAllReduce"));
+        api.CommDestroy  = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(api.handle, "ncclCommDestroy"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.handle); api.handle = NULL; }
+    });
+    return api.handle ? &api : NULL;
+}
+
+int map_nccl(ncclResult_t r)
+{
+    switch (r) {
+    case ncclSuccess:          return 0;
+    case ncclInvalidArgument:
+    case ncclInvalidUsage:     return EINVAL;
+    case ncclSystemError:
+    case ncclUnhandledCudaError:
+    case ncclInternalError:
+    default:                   return ECHILD;
+    }
+}
+
+} // namespace
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_comm_get_unique_id(unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES]) RMGR_NOEXCEPT
+{
+    static_assert(sizeof(ncclUniqueId) == RMGR_SSIM_HIP_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id) return EINVAL;
+    Rccl* r = rccl();
+    if (!r) return ENOSYS;
+    ncclUniqueId u;
+    const int rc = map_nccl(r->GetUniqueId(&u));
+    if (rc == 0) memcpy(id, &u, sizeof(u));
+    return rc;
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_comm_init(rmgr_ssim_hip_Context* c, const unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES],
+                                                rmgr_int32_t rankCount, rmgr_int32_t rank) RMGR_NOEXCEPT
+{
+    if (!c || !id || rankCount < 1 || rank < 0 || rank >= rankCount || c->comm) return EINVAL;
+    Rccl* r = rccl();
+    if (!r) return ENOSYS;
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    return map_nccl(r->CommInitRank(&c->comm, rankCount, u, rank));
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context* c, double* sumsDevice, rmgr_uint32_t count) RMGR_NOEXCEPT
+{
+    if (!c || !c->comm || (count && !sumsDevice)) return EINVAL;
+    if (count == 0) return 0;
+    Rccl* r = rccl();
+    if (!r) return ENOSYS;
+    HIP_TRY(hipSetDevice(c->device));
+    return map_nccl(r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    if (!c->comm) return 0;
+    Rccl* r = rccl();
+    const int rc = r ? map_nccl(r->CommDestroy(c->comm)) : ENOSYS;
+    c->comm = NULL;
+    return rc;
 }
 
 extern "C" {

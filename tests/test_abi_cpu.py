@@ -167,3 +167,18 @@ def test_reference_style_client_links_and_reports_enodev(tmp_path, manifest):
                          check=True, capture_output=True, text=True).stdout.splitlines()
     assert out[0] == "version 2.1.0 2.1.0"
     assert out[1:] == ["channel %d errno %d" % (c, errno.ENODEV) for c in range(3)]
+
+
+def test_install_layout_and_reference_link_line(tmp_path):
+    """`make install` gives the reference's layout (headers in include/rmgr, libs in lib),
+    and the reference's own link line (-lrmgr-ssim -lrmgr-ssim-openmp) resolves."""
+    prefix = tmp_path / "prefix"
+    subprocess.run(["make", "-C", ROOT, "install", "PREFIX=" + str(prefix)], check=True, stdout=subprocess.DEVNULL)
+    for rel in ("include/rmgr/ssim.h", "include/rmgr/ssim-openmp.h", "include/rmgr/ssim-version.h", "include/rmgr/ssim-hip.h",
+                "lib/librmgr-ssim-hip.so", "lib/librmgr-ssim.so", "lib/librmgr-ssim-openmp.so", "bin/rmgr-ssim", "lib/pkgconfig/rmgr-ssim.pc"):
+        assert (prefix / rel).exists(), rel
+    exe = tmp_path / "client"
+    subprocess.run(["g++", "-std=c++98", "-I", str(prefix / "include"), os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe),
+                    "-L", str(prefix / "lib"), "-lrmgr-ssim-openmp", "-lrmgr-ssim", "-Wl,-rpath," + str(prefix / "lib")], check=True)
+    r = subprocess.run([str(prefix / "bin" / "rmgr-ssim"), "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Usage: rmgr-ssim" in r.stdout

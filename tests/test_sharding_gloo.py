@@ -7,9 +7,6 @@ import sys
 
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,6 +20,8 @@ def image_sum(i):
 
 
 def worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
     sys.path.insert(0, ROOT)
     import ssim_amd
     from ssim_amd import sharding
@@ -42,6 +41,7 @@ def worker(rank, world, port, out_dir):
 
 
 def test_two_ranks_get_identical_complete_results(tmp_path):
+    import torch.multiprocessing as mp     # torch stays out of processes that only collect this file
     world = 2
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
