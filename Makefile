@@ -10,7 +10,9 @@ SRC     := ssim_amd/csrc
 OUT     := ssim_amd/lib
 OBJ     := build/obj
 BIN     := ssim_amd/bin
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(SRC) -Wall -Wno-unused-function
+# DOUBLE=1 builds the library with the reference's RMGR_SSIM_USE_DOUBLE semantics as the default mode
+# (CMakeLists.txt:53 of the reference); at run time RMGR_SSIM_HIP_MODE or rmgr_ssim_hip_set_mode override it.
+HIPFLAGS := $(if $(DOUBLE),-DRMGR_SSIM_USE_DOUBLE=1) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -I$(SRC) -Wall -Wno-unused-function
 
 all: lib oracle
 

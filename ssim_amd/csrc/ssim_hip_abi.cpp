@@ -326,9 +326,17 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t
     for (uint32_t i = 0; i < count; ++i)
         if (any_map && params[i].ssimMap == NULL) return EINVAL;   // all or none
     HIP_TRY(hipSetDevice(c->device));
-    std::vector<PairDesc> descs(count);
-    for (uint32_t i = 0; i < count; ++i) descs[i] = make_desc(params[i]);
-    return enqueue(c, params[0].width, params[0].height, count, descs.data(), any_map, sumsDevice);
+    // One launch covers up to 65535 pairs (grid.z); larger batches go out in consecutive launches.
+    const uint32_t kMaxPerLaunch = 65535;
+    std::vector<PairDesc> descs;
+    for (uint32_t first = 0; first < count; first += kMaxPerLaunch) {
+        const uint32_t n = std::min(kMaxPerLaunch, count - first);
+        descs.resize(n);
+        for (uint32_t i = 0; i < n; ++i) descs[i] = make_desc(params[first + i]);
+        const int rc = enqueue(c, params[0].width, params[0].height, n, descs.data(), any_map, sumsDevice + first);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT

@@ -30,7 +30,7 @@ def split_batch(total_pairs, world):
 def exchange_sums(sums_all, work, dist):
     """sums_all: float64 tensor [total pairs], zero outside this rank's slice.  Returns the tensor
     holding every rank's sums (work, all-reduced) -- or sums_all itself for a single process."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return sums_all
     work.copy_(sums_all)
     dist.all_reduce(work)

@@ -89,3 +89,25 @@ def test_double_mode_4k_config5(gpu_ctx, oracle, manifest):
         for d in keep:
             d.free()
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+
+
+def test_process_wide_mode_switch(manifest):
+    """RMGR_SSIM_HIP_MODE selects the arithmetic of the unchanged drop-in call (what RMGR_SSIM_USE_DOUBLE
+    does at build time in the reference, src/ssim_internal.h:26-37): mode 2 must return the double-mode value."""
+    import subprocess
+    import sys
+    ent = manifest["einstein_jpg"]
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import ssim_amd; "
+            "a=np.fromfile(%r,np.uint8).reshape(256,256); b=np.fromfile(%r,np.uint8).reshape(256,256); "
+            "print(repr(float(ssim_amd.compute_ssim(a,b)[0])))"
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(GOLDEN, ent["a"]), os.path.join(GOLDEN, ent["b"])))
+    out = {}
+    for mode in ("0", "2", "3"):
+        env = dict(os.environ, RMGR_SSIM_HIP_MODE=mode)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-800:]
+        out[mode] = float(r.stdout.split()[-1])
+    assert np.float32(out["0"]) == np.float32(float(ent["fma"]["ssim"]))
+    assert np.float32(out["3"]) == np.float32(float(ent["avx"]["ssim"]))
+    assert abs(out["2"] - float(ent["naive_f64"]["ssim"])) <= 6e-8 + 1e-9
+    assert out["2"] != out["0"]
