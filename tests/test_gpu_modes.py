@@ -48,6 +48,19 @@ def test_fast_mode_within_documented_tolerance(gpu_ctx, manifest, oracle, varian
     print("fast mode worst global %.3g, worst per-pixel %.3g" % (worst_g, worst_p))
 
 
+def test_fast_mode_full_size_4k(gpu_ctx, oracle):
+    """MODE_FAST at BASELINE's 4096^2 size: every pixel and the global value inside the tolerance."""
+    gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+    try:
+        a, b = oracle.synth_pair(4096, 4096, 0x5EED)
+        ov, _, om = oracle.ssim_f32(a, b, want_map=True, threads=oracle.oracle_lib().oracle_max_threads())
+        v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        assert abs(float(v) - float(ov)) <= GLOBAL_TOL
+        assert float(np.abs(m.astype(np.float64) - om.astype(np.float64)).max()) <= PIXEL_TOL
+    finally:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+
+
 def test_double_mode_vs_naive_oracle(gpu_ctx, manifest, oracle):
     gpu_ctx.set_mode(ssim_amd.MODE_DOUBLE)
     try:
