@@ -356,3 +356,19 @@ def test_native_rccl_exchange_single_rank():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "..", "tools", "rccl_selftest.py")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout.split(), (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("openmp", [False, True])
+@pytest.mark.parametrize("heap", [False, True])
+@pytest.mark.parametrize("want_map", [False, True])
+def test_reference_test_matrix_on_host_entry_points(manifest, openmp, heap, want_map):
+    """The reference's own test matrix (tests/rmgr-ssim-tests.cpp:468-507): {stack, heap} x {map, nomap} x
+    {serial, openmp} over every image set, here through the unchanged host-pointer entry points.  Where the
+    reference allows 2e-6 / 1e-3 against its naive oracle, the GPU path must match the FMA reference exactly."""
+    for name in image_entries(manifest):
+        ent = manifest[name]
+        a, b = load_pair(ent)
+        v, m = ssim_amd.compute_ssim(a, b, want_map=want_map, openmp=openmp, allocator=heap)
+        assert f32_hex(v) == ent["fma"]["ssim_hex"], name
+        if want_map:
+            assert sha(m) == ent["fma"]["map_sha256"], name
