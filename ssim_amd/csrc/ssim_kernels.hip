@@ -290,6 +290,8 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         offB[t] = xg * pd.b_step;
     }
 
+    // One row of pixels is in flight in registers (requested an iteration, ~1 us, before it is staged).
+    // A second row in flight was measured: no gain in MODE_EXACT, -3 % in MODE_FAST (registers).
     uint8_t va[NLOAD], vb[NLOAD];
     auto fetch = [&](int64_t r) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
         const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
@@ -332,62 +334,102 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     fetch(r_begin + 2);
     __syncthreads();
 
+    // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
+    // 2*lane+2): the two end pixels are 8-byte reads, the ten in between five 16-byte reads.  Only what is
+    // used is loaded (a dead half of a wide read gets its register reused and forces an early s_waitcnt).
+    f2 wab[14], wq[14], wxx[12];
+    const int e = 2 * lane + PAD - 6;                   // even: the 16-byte reads are aligned
+    auto load_ab = [&](const Slot2& s) {
+        // seven 16-byte reads; entries 0 and 13 are not used but are kept alive up to the folds (below):
+        // as 8-byte end reads the compiler moves them to the top of the loop, where their latency is exposed
+#pragma unroll
+        for (int t = 0; t < 7; ++t) {
+            const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
+            wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
+        }
+    };
+    load_ab(ring[0]);
+
     int cur = 0;
 #pragma unroll 1
     for (int64_t r = r_begin; r < r_end; ++r) {
         // One wave == one workgroup: the barriers only order LDS (they compile to nothing).
+        // LDS latency schedule of one row (the compiler only emits full s_waitcnt lgkmcnt(0) drains here,
+        // so the order of requests is arranged such that a drain never waits for much):
+        //   - the (a,b) window of this row was requested in the middle of the previous iteration;
+        //   - the (a*a,b*b) and ab windows are requested now and land behind the ~100 packed
+        //     instructions of the (a,b) streams;
+        //   - the next row's (a,b) window is requested as soon as this row's (a,b) streams are done.
         const Slot2& s = ring[cur];
-
-        // ---- window reads: this lane's two columns sit at slot pixels 2*lane+8, +9 ----
-        f2 wab[14], wq[14], wxx[12];
-        const int e = 2 * lane + PAD - 6;               // even: every read below is 16-byte aligned
-#pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
-            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-            wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
-            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-        }
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
-        }
-
-        // ---- blur: fold s[x+i]+s[x-i] (src/ssim_fma.cpp:196-201), then the row scatter ----
+        // (1) the folds of the (a,b) plane: their operands were requested an iteration ago, so the drain the
+        //     compiler puts in front of them finds nothing left to wait for
+        __builtin_amdgcn_sched_barrier(0);
+        f2 fa[2][5];
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int m = 6 + c;
-            const f2 a1 = wab[m + 1] + wab[m - 1], a2 = wab[m + 2] + wab[m - 2], a3 = wab[m + 3] + wab[m - 3],
-                     a4 = wab[m + 4] + wab[m - 4], a5 = wab[m + 5] + wab[m - 5];
+#pragma unroll
+            for (int i = 1; i <= 5; ++i) fa[c][i - 1] = wab[m + i] + wab[m - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
+        }
+        asm volatile("" :: "v"(wab[0]), "v"(wab[13]));   // see load_ab
+        // (2) request the other two planes of this row
+        __builtin_amdgcn_sched_barrier(0);
+        wq[1] = s.q[e + 1];
+#pragma unroll
+        for (int t = 1; t < 6; ++t) {
+            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+        }
+        wq[12] = s.q[e + 12];
+        wxx[1] = s.xx[e + 1];
+#pragma unroll
+        for (int t = 1; t < 6; ++t) {
+            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+        }
+        // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if constexpr (EXACT) blur_exact<FUSED>(accAB[c], wab[6 + c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+            else                 blur_separable(accAB[c], wab[6 + c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
+        }
+        // (4) the (a,b) window is dead now: refill it with the NEXT row's pixels (the other slot was staged an
+        //     iteration ago); the reads land behind the two remaining planes and the epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        load_ab(ring[cur ^ 1]);
+        // (5), (6) the remaining planes
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int m = 6 + c;
             const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
                      q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
-            if constexpr (EXACT) {
-                blur_exact<FUSED>(accAB[c], wab[m], a1, a2, a3, a4, a5);
-                blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
-            } else {
-                blur_separable(accAB[c], wab[m], a1, a2, a3, a4, a5, args.gf);
-                blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
-            }
+            if constexpr (EXACT) blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
+            else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
         }
+        __builtin_amdgcn_sched_barrier(0);
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
             if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
             else                 blur_separable(accX, wxx[6], x1, x2, x3, x4, x5, args.gf);
         }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- ring entry 0 is now the finished output row y = r - 5 (sum_tile) ----
+        // Branch-free on purpose: a conditional epilogue splits the loop body into basic blocks, the
+        // compiler then sinks most of the blur below the branch and the scheduling fences above lose
+        // their meaning.  During the 10 warm-up rows of a strip the values are computed and discarded.
         const int64_t y = r - 5;
-        if (y >= y0) {
+        const bool row_ok = y >= y0;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int64_t x = x0 + 2 * lane + c;
-                if (x < W) {
-                    const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
-                    colsum += (double)v;            // fp64 accumulation, src/ssim_avx.cpp:357-358
-                    if constexpr (MAP)
-                        ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
-                }
+        for (int c = 0; c < 2; ++c) {
+            const int64_t x = x0 + 2 * lane + c;
+            const bool ok = row_ok && x < W;
+            const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
+            colsum += ok ? (double)v : 0.0;         // fp64 accumulation, src/ssim_avx.cpp:357-358
+            if constexpr (MAP) {
+                if (ok) ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
             }
         }
         __syncthreads();
