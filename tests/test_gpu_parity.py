@@ -372,3 +372,45 @@ def test_reference_test_matrix_on_host_entry_points(manifest, openmp, heap, want
         assert f32_hex(v) == ent["fma"]["ssim_hex"], name
         if want_map:
             assert sha(m) == ent["fma"]["map_sha256"], name
+
+
+def test_dropin_call_is_thread_safe(manifest):
+    """The reference's compute_ssim is re-entrant (SURVEY.md 8(b) "Threading"); the drop-in call shares one
+    default context under a lock.  Hammer it from several host threads with different inputs."""
+    import threading
+    names = [n for n in image_entries(manifest)][:8]
+    pairs = [(load_pair(manifest[n]), manifest[n]["fma"]["ssim_hex"], manifest[n]["fma"]["map_sha256"]) for n in names]
+    errors = []
+
+    def work(tid):
+        try:
+            for it in range(12):
+                (a, b), want, want_map = pairs[(tid + it) % len(pairs)]
+                v, m = ssim_amd.compute_ssim(a, b, want_map=(it % 2 == 0))
+                if f32_hex(v) != want or (m is not None and sha(m) != want_map):
+                    errors.append((tid, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_two_contexts_and_mode_switching(gpu_ctx, manifest):
+    """Independent contexts (own stream, own scratch) coexist; switching modes on one does not leak into the other."""
+    ent = manifest["einstein_blur"]
+    a, b = load_pair(ent)
+    other = ssim_amd.Context(0, mode=ssim_amd.MODE_UNFUSED)
+    try:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+        for _ in range(3):
+            v0, _ = gpu_ctx.ssim_planes(a, b)
+            v1, _ = other.ssim_planes(a, b)
+            assert f32_hex(v0) == ent["fma"]["ssim_hex"] and f32_hex(v1) == ent["avx"]["ssim_hex"]
+        other.set_mode(ssim_amd.MODE_EXACT)
+        assert f32_hex(other.ssim_planes(a, b)[0]) == ent["fma"]["ssim_hex"]
+    finally:
+        other.close()
