@@ -374,18 +374,35 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         asm volatile("" :: "v"(wab[0]), "v"(wab[13]));   // see load_ab
         // (2) request the other two planes of this row
         __builtin_amdgcn_sched_barrier(0);
-        wq[1] = s.q[e + 1];
+        // Whole 16-byte reads where registers allow: 8-byte reads at this 16-byte lane stride are 2-way bank
+        // conflicts, but the three unused end entries of the wide form must be kept alive until their planes
+        // are consumed (see load_ab), and the map variant has no registers to spare (260 -> 1 wave/SIMD).
+        constexpr bool WIDE_ENDS = !MAP;
+        if constexpr (WIDE_ENDS) {
 #pragma unroll
-        for (int t = 1; t < 6; ++t) {
-            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-        }
-        wq[12] = s.q[e + 12];
-        wxx[1] = s.xx[e + 1];
+            for (int t = 0; t < 7; ++t) {
+                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+            }
 #pragma unroll
-        for (int t = 1; t < 6; ++t) {
-            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+            for (int t = 0; t < 6; ++t) {
+                const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+                wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+            }
+        } else {
+            wq[1] = s.q[e + 1];
+#pragma unroll
+            for (int t = 1; t < 6; ++t) {
+                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+            }
+            wq[12] = s.q[e + 12];
+            wxx[1] = s.xx[e + 1];
+#pragma unroll
+            for (int t = 1; t < 6; ++t) {
+                const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+                wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+            }
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -408,6 +425,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             if constexpr (EXACT) blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
             else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
         }
+        if constexpr (WIDE_ENDS) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
         __builtin_amdgcn_sched_barrier(0);
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];

@@ -40,9 +40,9 @@ def main():
         crow = list(csv.DictReader(open(path)))
         agg = collections.OrderedDict()
         for r in crow:
-            if "ssim_strip_kernel" in r["Kernel_Name"]:
+            if re.search(r"ssim_strip\d?_kernel", r["Kernel_Name"]):
                 agg.setdefault((r["Counter_Name"], r["Grid_Size"]), []).append(float(r["Counter_Value"]))
-        print("\n## counters: %s (per launch of ssim_strip_kernel)\n" % path.split("gpurun_out/")[-1])
+        print("\n## counters: %s (per launch of the strip kernel)\n" % path.split("gpurun_out/")[-1])
         print("| counter | grid | launches | mean value |")
         print("|---|---|---|---|")
         for (c, g), v in agg.items():
