@@ -15,7 +15,7 @@
  *
  * Every function cites the reference file:line it follows.  Nothing here is copied: the
  * reference processes 256x64 tiles through six scratch buffers and SIMD intrinsics; this
- * restatement streams whole-width 64-row bands through a per-row scatter, using the same
+ * restatement walks 256x64 tiles with a per-row scatter into plain row buffers, using the same
  * floating-point operations in the same order, which is what bit-exactness needs.
  *
  * Build: gcc -O3 -std=c99 -ffp-contract=off -fopenmp -mfma -mavx2 -shared -fPIC   (oracle/Makefile)
@@ -162,14 +162,14 @@ typedef struct {
 /* One source row r of the 5 statistic planes, edge-replicated by 5 px either side:
  * retrieve_tile (src/ssim.cpp:515-583: halo = nearest edge pixel of the IMAGE) and
  * multiply (src/ssim.cpp:249-265; products are exact for 8-bit inputs). */
-static void load_row32(const Job32* jb, int64_t r, float* pa, float* pb, float* paa, float* pbb, float* pab)
+static void load_row32(const Job32* jb, int64_t r, int64_t x0, int64_t tw, float* pa, float* pb, float* paa, float* pbb, float* pab)
 {
     const int64_t W = jb->width;
     const int64_t ry = clampi(r, 0, (int64_t)jb->height - 1);
     const uint8_t* ra = jb->a + ry * jb->a_stride;
     const uint8_t* rb = jb->b + ry * jb->b_stride;
-    for (int64_t xe = 0; xe < W + 2 * RADIUS; ++xe) {
-        const int64_t x = clampi(xe - RADIUS, 0, W - 1);
+    for (int64_t xe = 0; xe < tw + 2 * RADIUS; ++xe) {
+        const int64_t x = clampi(x0 + xe - RADIUS, 0, W - 1);
         const float a = (float)ra[x * jb->a_step];
         const float b = (float)rb[x * jb->b_step];
         pa[xe] = a;
@@ -183,37 +183,41 @@ static void load_row32(const Job32* jb, int64_t r, float* pa, float* pb, float* 
 /* The six per-row partial sums S_j(x), j=0..5, of one plane.  Horizontal fold
  * s[x+i]+s[x-i] (src/ssim_fma.cpp:196-201), then sum_j = s0*K(0,j) followed by five
  * multiply-adds in i order (:203-243).  fused: one rounding per step (VFMADD);
- * unfused: MUL_ADD(a,b,c) = a + b*c with both roundings (src/ssim.cpp:353). */
-static void row_sums32(const float* restrict p, int64_t W, const float* restrict k, int fused, float* restrict S /* [6][W] */)
+ * unfused: MUL_ADD(a,b,c) = a + b*c with both roundings (src/ssim.cpp:353).
+ * Written as plain loops over x on precomputed fold rows so that gcc vectorises them (the
+ * arithmetic per element is unchanged; -ffp-contract=off keeps the unfused form unfused). */
+static void row_sums32(const float* restrict p, int64_t W, const float* restrict k, int fused,
+                       float* restrict S /* [6][W] */, float* restrict F /* scratch [5][W] */)
 {
-    if (fused) {
-        for (int64_t x = 0; x < W; ++x) {
-            const float* s = p + x + RADIUS;
-            const float s0 = s[0];
-            const float s1 = s[1] + s[-1], s2 = s[2] + s[-2], s3 = s[3] + s[-3], s4 = s[4] + s[-4], s5 = s[5] + s[-5];
-            for (int j = 0; j <= RADIUS; ++j) {
-                float acc = s0 * k[tri(0, j)];
-                acc = fmaf(s1, k[tri(1, j)], acc);
-                acc = fmaf(s2, k[tri(2, j)], acc);
-                acc = fmaf(s3, k[tri(3, j)], acc);
-                acc = fmaf(s4, k[tri(4, j)], acc);
-                acc = fmaf(s5, k[tri(5, j)], acc);
-                S[j * W + x] = acc;
+    const float* restrict c = p + RADIUS;
+    for (int i = 1; i <= RADIUS; ++i) {
+        float* restrict f = F + (size_t)(i - 1) * W;
+        for (int64_t x = 0; x < W; ++x)
+            f[x] = c[x + i] + c[x - i];
+    }
+    const float* restrict f1 = F, *restrict f2 = F + W, *restrict f3 = F + 2 * W, *restrict f4 = F + 3 * W, *restrict f5 = F + 4 * W;
+    for (int j = 0; j <= RADIUS; ++j) {
+        const float k0 = k[tri(0, j)], k1 = k[tri(1, j)], k2 = k[tri(2, j)], k3 = k[tri(3, j)], k4 = k[tri(4, j)], k5 = k[tri(5, j)];
+        float* restrict s = S + (size_t)j * W;
+        if (fused) {
+            for (int64_t x = 0; x < W; ++x) {
+                float acc = c[x] * k0;
+                acc = fmaf(f1[x], k1, acc);
+                acc = fmaf(f2[x], k2, acc);
+                acc = fmaf(f3[x], k3, acc);
+                acc = fmaf(f4[x], k4, acc);
+                acc = fmaf(f5[x], k5, acc);
+                s[x] = acc;
             }
-        }
-    } else {
-        for (int64_t x = 0; x < W; ++x) {
-            const float* s = p + x + RADIUS;
-            const float s0 = s[0];
-            const float s1 = s[1] + s[-1], s2 = s[2] + s[-2], s3 = s[3] + s[-3], s4 = s[4] + s[-4], s5 = s[5] + s[-5];
-            for (int j = 0; j <= RADIUS; ++j) {
-                float acc = s0 * k[tri(0, j)];
-                acc = acc + s1 * k[tri(1, j)];
-                acc = acc + s2 * k[tri(2, j)];
-                acc = acc + s3 * k[tri(3, j)];
-                acc = acc + s4 * k[tri(4, j)];
-                acc = acc + s5 * k[tri(5, j)];
-                S[j * W + x] = acc;
+        } else {
+            for (int64_t x = 0; x < W; ++x) {
+                float acc = c[x] * k0;
+                acc = acc + f1[x] * k1;
+                acc = acc + f2[x] * k2;
+                acc = acc + f3[x] * k3;
+                acc = acc + f4[x] * k4;
+                acc = acc + f5[x] * k5;
+                s[x] = acc;
             }
         }
     }
@@ -250,22 +254,24 @@ static double tile_sum_avx_order(const float* ssim, int64_t stride, int64_t tw, 
     return tileSum;
 }
 
-/* One 64-row band [y0, y0+bh): blur the five planes by row scatter, then the per-pixel
- * SSIM.  Writes the band's SSIM values to `ssim` (bh x W, dense) and to the caller's map. */
-static void band32(const Job32* jb, int64_t y0, int64_t bh, float* work, float* ssim)
+/* One tile [x0, x0+tw) x [y0, y0+bh) (at most 256 x 64, the reference's tile so that the working set
+ * stays in cache): blur the five planes by row scatter, then the per-pixel SSIM.  Writes the tile's
+ * SSIM values to `ssim` (bh x tw, dense) and to the caller's map.  Results do not depend on the tiling:
+ * the halo is the image's, not the tile's. */
+static void tile32(const Job32* jb, int64_t x0, int64_t tw, int64_t y0, int64_t bh, float* work, float* ssim)
 {
-    const int64_t W = jb->width;
-    const int64_t EW = W + 2 * RADIUS;
-    float* rows = work;               /* 5 planes x EW   */
-    float* S = rows + 5 * EW;         /* 6 x W           */
-    float* dst = S + 6 * W;           /* 5 planes x bh x W */
-    memset(dst, 0, sizeof(float) * 5 * (size_t)bh * (size_t)W); /* memset per dest row, src/ssim_fma.cpp:187 */
+    const int64_t EW = tw + 2 * RADIUS;
+    float* rows = work;               /* 5 planes x EW    */
+    float* S = rows + 5 * EW;         /* 6 x tw           */
+    float* F = S + 6 * tw;            /* 5 x tw fold rows */
+    float* dst = F + 5 * tw;          /* 5 planes x bh x tw */
+    memset(dst, 0, sizeof(float) * 5 * (size_t)bh * (size_t)tw); /* memset per dest row, src/ssim_fma.cpp:187 */
 
     for (int64_t r = y0 - RADIUS; r < y0 + bh + RADIUS; ++r) {
-        load_row32(jb, r, rows, rows + EW, rows + 2 * EW, rows + 3 * EW, rows + 4 * EW);
+        load_row32(jb, r, x0, tw, rows, rows + EW, rows + 2 * EW, rows + 3 * EW, rows + 4 * EW);
         for (int p = 0; p < 5; ++p) {
-            row_sums32(rows + p * EW, W, jb->k, jb->fused, S);
-            float* dp = dst + (size_t)p * bh * W;
+            row_sums32(rows + p * EW, tw, jb->k, jb->fused, S, F);
+            float* dp = dst + (size_t)p * bh * tw;
             /* scatter: rows r-5..r+5 of dest += sum5,sum4,..,sum0,..,sum5 (src/ssim_fma.cpp:246-257).
              * Each dest row therefore receives its 11 addends in source-row order, top first. */
             for (int dy = -RADIUS; dy <= RADIUS; ++dy) {
@@ -273,9 +279,9 @@ static void band32(const Job32* jb, int64_t y0, int64_t bh, float* work, float* 
                 if (y < y0 || y >= y0 + bh)
                     continue;
                 const int j = dy < 0 ? -dy : dy;
-                float* d = dp + (y - y0) * W;
-                const float* sj = S + j * W;
-                for (int64_t x = 0; x < W; ++x)
+                float* restrict d = dp + (y - y0) * tw;
+                const float* restrict sj = S + j * tw;
+                for (int64_t x = 0; x < tw; ++x)
                     d[x] = sj[x] + d[x];
             }
         }
@@ -283,15 +289,15 @@ static void band32(const Job32* jb, int64_t y0, int64_t bh, float* work, float* 
 
     const float c1 = jb->c1, c2 = jb->c2;
     const float* muA = dst;
-    const float* muB = dst + (size_t)bh * W;
-    const float* eAA = dst + 2 * (size_t)bh * W;
-    const float* eBB = dst + 3 * (size_t)bh * W;
-    const float* eAB = dst + 4 * (size_t)bh * W;
+    const float* muB = dst + (size_t)bh * tw;
+    const float* eAA = dst + 2 * (size_t)bh * tw;
+    const float* eBB = dst + 3 * (size_t)bh * tw;
+    const float* eAB = dst + 4 * (size_t)bh * tw;
     for (int64_t y = 0; y < bh; ++y) {
-        for (int64_t x = 0; x < W; ++x) {
+        for (int64_t x = 0; x < tw; ++x) {
             /* src/ssim.cpp:681-693 == src/ssim_avx.cpp:342-352 (the AVX form negates both
              * sigma factors, which cancels exactly in the quotient). */
-            const size_t o = (size_t)y * W + x;
+            const size_t o = (size_t)y * tw + x;
             const float a = muA[o], b = muB[o];
             const float muA2 = a * a, muB2 = b * b, muAB = a * b;
             const float sA2 = eAA[o] - muA2, sB2 = eBB[o] - muB2, sAB = eAB[o] - muAB;
@@ -300,7 +306,7 @@ static void band32(const Job32* jb, int64_t y0, int64_t bh, float* work, float* 
             const float v = num / den;
             ssim[o] = v;
             if (jb->map)
-                jb->map[(y0 + y) * jb->map_stride + x * jb->map_step] = v;
+                jb->map[(y0 + y) * jb->map_stride + (x0 + x) * jb->map_step] = v;
         }
     }
 }
@@ -338,23 +344,21 @@ int oracle_ssim_f32(float* ssim_out, double* sum_out, uint32_t width, uint32_t h
         threads = 1;
 #pragma omp parallel num_threads(threads)
     {
-        const size_t workN = (size_t)5 * (W + 2 * RADIUS) + (size_t)6 * W + (size_t)5 * BAND_H * W;
+        const size_t workN = (size_t)5 * (TILE_W + 2 * RADIUS) + (size_t)11 * TILE_W + (size_t)5 * BAND_H * TILE_W;
         float* work = (float*)malloc(sizeof(float) * (workN + 16));
-        float* ssim = (float*)malloc(sizeof(float) * ((size_t)BAND_H * W + 16));
+        float* ssim = (float*)malloc(sizeof(float) * ((size_t)BAND_H * TILE_W + 16));
         if (!work || !ssim) {
 #pragma omp atomic write
             err = 12;
         } else {
-#pragma omp for schedule(dynamic, 1)
-            for (int64_t bi = 0; bi < bands; ++bi) {
-                const int64_t y0 = bi * BAND_H;
+#pragma omp for schedule(dynamic, 4)
+            for (int64_t t = 0; t < bands * tilesX; ++t) {
+                const int64_t bi = t / tilesX, tx = t % tilesX;
+                const int64_t y0 = bi * BAND_H, x0 = tx * TILE_W;
                 const int64_t bh = (H - y0 < BAND_H) ? H - y0 : BAND_H;
-                band32(&jb, y0, bh, work, ssim);
-                for (int64_t tx = 0; tx < tilesX; ++tx) {
-                    const int64_t x0 = tx * TILE_W;
-                    const int64_t tw = (W - x0 < TILE_W) ? W - x0 : TILE_W;
-                    tileSums[bi * tilesX + tx] = tile_sum_avx_order(ssim + x0, W, tw, bh);
-                }
+                const int64_t tw = (W - x0 < TILE_W) ? W - x0 : TILE_W;
+                tile32(&jb, x0, tw, y0, bh, work, ssim);
+                tileSums[t] = tile_sum_avx_order(ssim, tw, tw, bh);
             }
         }
         free(work);
