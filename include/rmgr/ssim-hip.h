@@ -36,6 +36,9 @@ extern "C" {
 #define RMGR_SSIM_HIP_MODE_DOUBLE  2  /* RMGR_SSIM_USE_DOUBLE semantics: fp64 internals, true double kernel (tests/ssim_naive.h) */
 #define RMGR_SSIM_HIP_MODE_UNFUSED 3  /* operation order of the reference's AVX/SSE/generic paths (mul and add rounded separately) */
 
+/* An engine instance: one device, one stream, its own grow-only scratch.  A context may be used by one
+ * host thread at a time (create one per thread, or serialise); the NULL / default context of the
+ * host-pointer entry points is shared process-wide and locked internally. */
 typedef struct rmgr_ssim_hip_Context_ rmgr_ssim_hip_Context;
 
 /* Number of usable HIP devices (0 when none; never fails). */
