@@ -182,3 +182,11 @@ def test_install_layout_and_reference_link_line(tmp_path):
                     "-L", str(prefix / "lib"), "-lrmgr-ssim-openmp", "-lrmgr-ssim", "-Wl,-rpath," + str(prefix / "lib")], check=True)
     r = subprocess.run([str(prefix / "bin" / "rmgr-ssim"), "-h"], capture_output=True, text=True)
     assert r.returncode == 0 and "Usage: rmgr-ssim" in r.stdout
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_bench_refuses_to_run_without_the_gpu():
+    """bench.py measures the HIP path or nothing: no device -> a loud non-zero exit, never a CPU number."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
+    assert "metric" not in r.stdout

@@ -1,6 +1,6 @@
 """CPU: the oracle (oracle/ssim_oracle.c) against the committed golden vectors.
 
-Golden vectors = what the reference itself produced (tools/make_fixtures.py, real FMA/AVX kernel
+Golden vectors = what the reference itself produced (tests/tools/make_fixtures.py, real FMA/AVX kernel
 objects + tests/ssim_naive.h) on the reference's own test images, plus the quad-precision
 constants of the reference's tests (tests/rmgr-ssim-tests.cpp:352-360).
 """

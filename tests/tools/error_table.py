@@ -7,7 +7,7 @@ tests/golden): average / maximum error of the global SSIM and of the per-pixel m
 naive double-precision oracle (tests/ssim_naive.h semantics), and Mpix/s through the drop-in call
 (host pointers) with and without a map.  Runs on the GPU box; uses the oracle as the checker.
 
-usage: python tools/error_table.py > profiles/<round>_error_table.md
+usage: python tests/tools/error_table.py > profiles/<round>_error_table.md
 """
 import json
 import os
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402  (checker)
 import ssim_amd  # noqa: E402
