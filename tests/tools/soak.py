@@ -1,0 +1,39 @@
+"""One-off randomized soak of the GPU path against the oracle: 300 random sizes / layouts / modes /
+kernel variants (run on the GPU box: python tests/tools/soak.py).  Last run: 0 failures."""
+import sys, numpy as np, ctypes
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+import ssim_amd, oracle
+from test_gpu_fuzz import make_layout
+rng=np.random.default_rng(777)
+ctx=ssim_amd.Context(0)
+lib=oracle.oracle_lib()
+bad=0
+for case in range(300):
+    big = case % 10 == 0
+    h,w=(int(rng.integers(200,1400)),int(rng.integers(300,2100))) if big else (int(rng.integers(1,260)),int(rng.integers(1,400)))
+    a=rng.integers(0,256,(h,w),dtype=np.uint8)
+    b=np.clip(a.astype(np.int32)+rng.integers(-40,41,(h,w)),0,255).astype(np.uint8)
+    mode=int(rng.choice([0,0,0,3,1,2]))
+    ba,oa,sa,da_=make_layout(rng,a); bb,ob,sb,db_=make_layout(rng,b)
+    variant=int(rng.integers(0,2)); rows=int(rng.choice([0,0,2,9,31,64,300]))
+    keep=[]
+    try:
+        da,db=ctx.upload(ba),ctx.upload(bb); dm=ctx.alloc(4*w*h); keep+=[da,db,dm]
+        p=ssim_amd.make_params(w,h,da.ptr+oa,sa,da_,db.ptr+ob,sb,db_,dm.ptr,1,w)
+        ctx.set_mode(mode); ctx.set_tuning(rows,variant)
+        v=ctx.compute_device(p); m=dm.download(np.float32,(h,w))
+    finally:
+        for d in keep: d.free()
+    if mode in (0,3):
+        ov,_,om=oracle.ssim_f32(a,b,want_map=True,fused=(mode==0),threads=8)
+        ok=np.array_equal(m.view(np.uint32),om.view(np.uint32)) and abs(int(np.float32(v).view(np.int32))-int(np.float32(ov).view(np.int32)))<=1
+    elif mode==1:
+        ov,_,om=oracle.ssim_f32(a,b,want_map=True,threads=8)
+        ok=abs(float(v)-float(ov))<=1.5e-6 and np.abs(m.astype(np.float64)-om).max()<=6.3e-4
+    else:
+        if h*w>60000: continue
+        nv,_,nm=oracle.ssim_naive_f64(a,b,want_map=True,threads=8)
+        ok=abs(float(v)-nv)<=7e-8 and np.abs(m.astype(np.float64)-nm).max()<=1e-7
+    if not ok:
+        bad+=1; print('FAIL',case,w,h,mode,variant,rows,sa,da_,sb,db_, float(v))
+print('soak done, failures:',bad)
