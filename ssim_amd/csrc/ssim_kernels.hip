@@ -192,6 +192,15 @@ struct KArgs {
     double          gd[6];        // separable taps, fp64
 };
 
+// One workgroup is one wavefront, and a wave's LDS operations execute in issue order, so lanes only need
+// the COMPILER to keep LDS accesses in program order across this point -- no s_barrier, and above all no
+// s_waitcnt: __syncthreads() makes the wave drain its just-issued staging writes (~150 cycles per row).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // What every strip kernel does first: find its strip and its image pair.
 struct Strip {
     PairDesc pd;                 // wave-uniform (SGPRs)
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     fetch(r_begin + 1);
     stage(ring[1]);
     fetch(r_begin + 2);
-    __syncthreads();
+    wave_sync();
 
     // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
     // 2*lane+2): the two end pixels are 8-byte reads, the ten in between five 16-byte reads.  Only what is
@@ -348,31 +357,36 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
         }
     };
-    load_ab(ring[0]);
-
-    int cur = 0;
-#pragma unroll 1
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        // One wave == one workgroup: the barriers only order LDS (they compile to nothing).
-        // LDS latency schedule of one row (the compiler only emits full s_waitcnt lgkmcnt(0) drains here,
-        // so the order of requests is arranged such that a drain never waits for much):
-        //   - the (a,b) window of this row was requested in the middle of the previous iteration;
-        //   - the (a*a,b*b) and ab windows are requested now and land behind the ~100 packed
-        //     instructions of the (a,b) streams;
-        //   - the next row's (a,b) window is requested as soon as this row's (a,b) streams are done.
-        const Slot2& s = ring[cur];
-        // (1) the folds of the (a,b) plane: their operands were requested an iteration ago, so the drain the
-        //     compiler puts in front of them finds nothing left to wait for
-        __builtin_amdgcn_sched_barrier(0);
-        f2 fa[2][5];
+    // Folded (a,b) sums of the row about to be blurred, and its two centre pixels: computed at the END of the
+    // previous iteration (where the window reads they consume are long complete) and carried over the loop edge.
+    f2 fa[2][5], ca[2];
+    auto fold_ab = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int m = 6 + c;
+            ca[c] = wab[m];
 #pragma unroll
             for (int i = 1; i <= 5; ++i) fa[c][i - 1] = wab[m + i] + wab[m - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
         }
         asm volatile("" :: "v"(wab[0]), "v"(wab[13]));   // see load_ab
-        // (2) request the other two planes of this row
+    };
+    load_ab(ring[0]);
+    fold_ab();
+
+    int cur = 0;
+#pragma unroll 1
+    for (int64_t r = r_begin; r < r_end; ++r) {
+        // One wave == one workgroup: wave_sync() only orders LDS accesses for the compiler.
+        // LDS latency schedule of one row.  The compiler emits a full s_waitcnt lgkmcnt(0) drain whenever it
+        // cannot count (more than 15 operations in flight, or at the loop header), so requests and first uses
+        // are placed such that no drain ever waits for much:
+        //   - the (a*a,b*b) and ab windows of this row are requested first and land behind the ~100 packed
+        //     instructions of the (a,b) streams, which start immediately from the carried-over folds;
+        //   - the next row's (a,b) window is requested between the (a*a,b*b) and the ab streams, and is
+        //     folded at the bottom of the iteration, BEFORE the staging writes of row r+2 are issued
+        //     (a drain at the loop header would otherwise wait for those writes).
+        const Slot2& s = ring[cur];
+        // (1), (2) request the other two planes of this row
         __builtin_amdgcn_sched_barrier(0);
         // Whole 16-byte reads where registers allow: 8-byte reads at this 16-byte lane stride are 2-way bank
         // conflicts, but the three unused end entries of the wide form must be kept alive until their planes
@@ -408,14 +422,10 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            if constexpr (EXACT) blur_exact<FUSED>(accAB[c], wab[6 + c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
-            else                 blur_separable(accAB[c], wab[6 + c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
+            if constexpr (EXACT) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+            else                 blur_separable(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
         }
-        // (4) the (a,b) window is dead now: refill it with the NEXT row's pixels (the other slot was staged an
-        //     iteration ago); the reads land behind the two remaining planes and the epilogue
-        __builtin_amdgcn_sched_barrier(0);
-        load_ab(ring[cur ^ 1]);
-        // (5), (6) the remaining planes
+        // (4) the (a*a,b*b) streams
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -426,6 +436,11 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
         }
         if constexpr (WIDE_ENDS) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
+        // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
+        //     with more than 15 LDS operations in flight the compiler can only drain them all.
+        __builtin_amdgcn_sched_barrier(0);
+        load_ab(ring[cur ^ 1]);
+        // (6) the ab stream
         __builtin_amdgcn_sched_barrier(0);
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
@@ -450,10 +465,13 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
                 if (ok) ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        fold_ab();                                  // row r+1 (window requested in step (4))
+        __builtin_amdgcn_sched_barrier(0);
+        wave_sync();
         stage(ring[cur]);                           // row r+2 replaces row r
         fetch(r + 3);
-        __syncthreads();
+        wave_sync();
         cur ^= 1;
     }
     strip_finish(args, st, colsum);
