@@ -564,7 +564,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         // then row r is consumed.
         stage(ring[cur ^ 1]);
         fetch(r + 2);
-        __syncthreads();
+        wave_sync();
         const Slot1& s = ring[cur];
 
         f2 wab[11], wq[11];
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
             if constexpr (MAP)
                 ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = vmap;
         }
-        __syncthreads();
+        wave_sync();
         cur ^= 1;
     }
     strip_finish(args, st, colsum);
