@@ -131,6 +131,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
+    # Everything (torch ops, RCCL, our launches) is ordered on one explicit non-default stream: the legacy
+    # NULL stream adds implicit synchronisation to every launch.
+    if os.environ.get("SSIM_BENCH_NULL_STREAM") != "1":
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = torch.cuda.current_stream()
     ctx = ssim_amd.Context(local_rank, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
     ctx.set_tuning(args.strip_rows, args.variant)
