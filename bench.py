@@ -74,24 +74,61 @@ def cpu_baseline(budget_s=12.0):
     t_single = time.perf_counter() - t1
     del oracle_1t
     best = min(times)
+    model, procs = host_cpu()
     return {"value": round(W * H / best / 1e6, 1), "unit": "Mpix/s", "cores": cores, "kind": kind,
+            "cpu_model": model, "logical_cpus": procs, "one_thread_mpix_s": round(W * H / t_single / 1e6, 1),
             "sample": "%d back-to-back runs of one 4096x4096 pair (seed 0x5EED) over ~12 s, best run reported; median %.1f Mpix/s; 1 thread %.1f Mpix/s; %s"
                       % (len(times), W * H / statistics.median(times) / 1e6, W * H / t_single / 1e6,
                          "real reference FMA/AVX kernel objects (oracle/_ref) driven by the harness tile loop, OpenMP static schedule"
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
-def measured_traffic(mode, pairs):
+def measured_traffic(mode, workload, pairs):
     """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json), scaled to
     this batch; None when no measurement exists for the configuration."""
+    key = {"4k": "exact_4096_nomap", "8k-map": "exact_8192_map", "1080p": "exact_1080p_nomap"}.get(workload)
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        if mode == 0 and "exact_4096_nomap" in t:
-            return float(t["exact_4096_nomap"]["bytes_per_pair"]) * pairs
+        if mode == 0 and key in t:
+            return float(t[key]["bytes_per_pair"]) * pairs
     except (OSError, ValueError, KeyError):
         pass
     return None
+
+
+def attainable_hbm_gbs(torch, dev):
+    """What a plain device-to-device copy reaches on this box (SURVEY 8d asks for the attainable figure next
+    to the 8 TB/s spec): 1 GiB read + 1 GiB written per copy, HIP events, best of 10."""
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).fill_(3)
+    dst = torch.empty_like(src)
+    best = None
+    for _ in range(3):
+        dst.copy_(src)
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None else min(best, ms)
+    del src, dst
+    return round(2.0 * n / (best * 1e-3) / 1e9, 1)
+
+
+def host_cpu():
+    model, procs = "unknown", os.cpu_count()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("model name"):
+                    model = l.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, procs
 
 
 def main():
@@ -256,6 +293,9 @@ def main():
         ctx.enqueue_batch(params, P, my_slice_ptr)      # restore the slice for consistency
         torch.cuda.synchronize()
 
+    attainable = None
+    if rank == 0:
+        attainable = attainable_hbm_gbs(torch, dev)
     if rank == 0:
         pixels = float(world) * P * W * H * args.steps
         value = pixels / elapsed / 1e6
@@ -274,7 +314,8 @@ def main():
                        "mode": ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double", "unfused"][args.mode],
                        "pairs_per_gpu": P, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, P) if args.workload == "4k" else None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, args.workload, P),
+                         "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
                          "kernel": "ssim_strip1_kernel" if (args.mode == 2 or args.variant == 1) else "ssim_strip2_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"},

@@ -147,7 +147,10 @@ int drain_profile(rmgr_ssim_hip_Context* c)
 // Enqueue kernel + reduction for `count` pairs whose descriptors are in `descs` (host).
 int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev)
 {
-    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count);
+    int variant = c->variant;
+    for (uint32_t i = 0; i < count && variant != 1; ++i)
+        if (!ssim_hip::fits_strip2(descs[i], width, height)) variant = 1;
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count);
     int rc = grow_device(c->partials, c->partials_cap, (size_t)count * geo.partials_per_image() + 1);
     if (rc) return rc;
     PairDesc single = descs[0];
@@ -170,7 +173,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     }
     hipEvent_t eb, ee;
     if ((rc = record_begin(c, eb, ee))) return rc;
-    HIP_TRY(ssim_hip::launch(geo, c->mode, c->variant, descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
+    HIP_TRY(ssim_hip::launch(geo, c->mode, variant, descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
     return 0;
 }
 

@@ -27,6 +27,17 @@ struct Geometry {
     uint32_t partials_per_image() const { return strips_x * strips_y; }
 };
 
+// The two-column kernel addresses a strip's pixels as (64-bit uniform row base) + (32-bit lane offset) and keeps
+// its coordinates in 32-bit registers; a pair outside these (enormous) ranges runs on the one-column kernel,
+// which is fully 64-bit: pass variant 1 to plan()/launch() when this returns false.
+inline bool fits_strip2(const PairDesc& d, uint32_t width, uint32_t height)
+{
+    const int64_t lim = int64_t(1) << 21;     // 144 columns x |step| x 4 B (map) stays below 2^31
+    return width < 0x7FFF0000u && height < 0x7FFF0000u &&
+           d.a_step > -lim && d.a_step < lim && d.b_step > -lim && d.b_step < lim &&
+           (d.map == 0 || (d.map_step > -lim && d.map_step < lim));
+}
+
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
 Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count);
 

@@ -181,6 +181,58 @@ __device__ __forceinline__ double ssim_px(double muA, double muB, double eAA, do
     return num / den;
 }
 
+// Correctly rounded n/d for operands that need none of v_div_scale / v_div_fixup: the instruction sequence the
+// compiler emits for an IEEE float division, minus its range handling.  v_div_scale_f32 rescales only when an
+// operand or the quotient is denormal, |exponent(n) - exponent(d)| >= 96, or d is within 2^3 of overflow, and
+// v_div_fixup_f32 only replaces the result for zero / infinite / NaN operands (a zero numerator included, for
+// which the sequence below also yields +0).  Here d = (muA^2+muB^2+c1)(sA^2+sB^2+c2) lies in [2^8, 2^35]
+// (the variances carry at most ~0.1 of negative rounding noise against c2 = 58.5) and n =
+// (2 muAB + c1)(2 sAB + c2) is 0 or has 2^-16 <= |n| <= 2^35 (2 sAB + c2 is a multiple of 2^-18 whenever it
+// is small), so every intermediate below is the one the full sequence would produce: bit-identical quotients,
+// two at a time in packed fp32.
+__device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
+
+// First half: the refined reciprocal of d; second half: the quotient and its two correction steps.
+__device__ __forceinline__ f2 div_inrange_rcp(f2 d)
+{
+    const f2 one = {1.0f, 1.0f};
+    const f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return fma_(fma_(-d, r, one), r, r);
+}
+__device__ __forceinline__ f2 div_inrange_finish(f2 n, f2 d, f2 r)
+{
+    f2 q = n * r;
+    q = fma_(fma_(-d, q, n), r, q);
+    return fma_(fma_(-d, q, n), r, q);
+}
+
+// ssim_px for the two columns of a lane at once: (muA,muB) and (E[a^2],E[b^2]) arrive packed per column,
+// E[ab] packed across the columns.  Same operations, same roundings as the scalar form above.  In two parts:
+// everything that does not involve E[ab] -- the denominator and its refined reciprocal -- is issued together
+// with the ab stream's blur (independent work to hide the dependent chain behind), the rest after it.
+struct Px2 { f2 muAB, den, rcp; };
+__device__ __forceinline__ Px2 ssim_px2_head(f2 mu0, f2 mu1, f2 e0, f2 e1, float c1, float c2)
+{
+    const f2 m0 = mu0 * mu0, m1 = mu1 * mu1;             // (muA^2, muB^2) per column
+    const f2 s0 = e0 - m0, s1 = e1 - m1;                 // (sA^2, sB^2)
+    // the cross-half terms stay scalar instructions (opaque(): keeps the vector combiner from turning them
+    // into shuffles + packed ops); their results land in adjacent registers and continue packed
+    Px2 h;
+    h.muAB = f2{opaque(mu0.x * mu0.y), opaque(mu1.x * mu1.y)};
+    const f2 C1 = {c1, c1}, C2 = {c2, c2};
+    const f2 tm = {opaque(m0.x + m0.y), opaque(m1.x + m1.y)}, ts = {opaque(s0.x + s0.y), opaque(s1.x + s1.y)};
+    h.den = (tm + C1) * (ts + C2);
+    h.rcp = div_inrange_rcp(h.den);
+    return h;
+}
+__device__ __forceinline__ f2 ssim_px2_tail(const Px2& h, f2 eAB, float c1, float c2)
+{
+    const f2 two = {2.0f, 2.0f}, C1 = {c1, c1}, C2 = {c2, c2};
+    const f2 sAB = eAB - h.muAB;
+    const f2 n = fma_(two, h.muAB, C1) * fma_(two, sAB, C2);
+    return div_inrange_finish(n, h.den, h.rcp);
+}
+
 struct KArgs {
     PairDesc        single;       // used when descs == nullptr
     const PairDesc* descs;
@@ -282,32 +334,43 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     const int lane = threadIdx.x;
     const Strip st = strip_setup(args, Slot2::STRIP_W);
     const PairDesc& pd = st.pd;
-    const int64_t W = st.W, H = st.H, x0 = st.x0, y0 = st.y0, y_end = st.y_end;
+    // 32-bit coordinates (fits_strip2() on the host guarantees the ranges): row bookkeeping stays on the
+    // scalar unit -- there are no 64-bit scalar ordered compares, so int64 loop counters cost VALU work.
+    const int W = (int)st.W, H = (int)st.H, x0 = (int)st.x0, y0 = (int)st.y0, y_end = (int)st.y_end;
 
     // Per-lane staging columns: pixel p of the slot is image column clamp(x0 - PAD + p)
-    // (edge replication of the IMAGE, src/ssim.cpp:529-554).
-    int     sp[NLOAD];
-    int64_t offA[NLOAD], offB[NLOAD];
+    // (edge replication of the IMAGE, src/ssim.cpp:529-554).  Addresses are a wave-uniform row base
+    // (SGPR pair) plus a non-negative 32-bit lane offset from the strip's lowest-addressed column, the
+    // global_load "saddr" form: nothing but the load itself is issued per row and per pixel.
+    auto clampx = [&](int x) { return x < 0 ? 0 : (x > W - 1 ? W - 1 : x); };
+    const int x_lo = clampx(x0 - PAD), x_hi = clampx(x0 - PAD + ROW_PX - 1);
+    const int refA = pd.a_step >= 0 ? x_lo : x_hi, refB = pd.b_step >= 0 ? x_lo : x_hi;
+    const gptr_u8 baseA = (gptr_u8)pd.a + (int64_t)refA * pd.a_step;
+    const gptr_u8 baseB = (gptr_u8)pd.b + (int64_t)refB * pd.b_step;
+    int      sp[NLOAD];
+    uint32_t offA[NLOAD], offB[NLOAD];
 #pragma unroll
     for (int t = 0; t < NLOAD; ++t) {
         int p = lane + 64 * t;
         p = p < ROW_PX ? p : ROW_PX - 1;
-        int64_t xg = x0 - PAD + p;
-        xg = xg < 0 ? 0 : (xg > W - 1 ? W - 1 : xg);
+        const int xg = clampx(x0 - PAD + p);
         sp[t] = p;
-        offA[t] = xg * pd.a_step;
-        offB[t] = xg * pd.b_step;
+        offA[t] = (uint32_t)((int64_t)(xg - refA) * pd.a_step);
+        offB[t] = (uint32_t)((int64_t)(xg - refB) * pd.b_step);
     }
 
     // One row of pixels is in flight in registers (requested an iteration, ~1 us, before it is staged).
     // A second row in flight was measured: no gain in MODE_EXACT, -3 % in MODE_FAST (registers).
     uint8_t va[NLOAD], vb[NLOAD];
-    auto fetch = [&](int64_t r) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
-        const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        const gptr_u8 ra = (gptr_u8)pd.a + ry * pd.a_stride;
-        const gptr_u8 rb = (gptr_u8)pd.b + ry * pd.b_stride;
+    auto fetch = [&](int r) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
+        const int ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
+        const gptr_u8 ra = baseA + (int64_t)ry * pd.a_stride;
+        const gptr_u8 rb = baseB + (int64_t)ry * pd.b_stride;
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
+            // The empty asm keeps the zero-extension of the offset inside the loop body, where instruction
+            // selection can fold it into the load (hoisted, it becomes a 64-bit VGPR pair and a 64-bit add).
+            asm volatile("" : "+v"(offA[t]), "+v"(offB[t]));
             va[t] = ra[offA[t]];
             vb[t] = rb[offB[t]];
         }
@@ -335,13 +398,24 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     }
     double colsum = 0.0;
 
-    const int64_t r_begin = y0 - 5, r_end = y_end + 5;
+    const int r_begin = y0 - 5, r_end = y_end + 5;
     fetch(r_begin);
     stage(ring[0]);
     fetch(r_begin + 1);
     stage(ring[1]);
     fetch(r_begin + 2);
     wave_sync();
+
+    // Map addressing, like the loads: uniform row base + non-negative 32-bit byte offset per column.
+    const int refM = pd.map_step >= 0 ? x0 : (x0 + Slot2::STRIP_W - 1 < W ? x0 + Slot2::STRIP_W - 1 : W - 1);
+    uint32_t offM[2] = {0, 0};
+    bool     col_ok[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int x = x0 + 2 * lane + c;
+        col_ok[c] = x < W;
+        if constexpr (MAP) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0u;
+    }
 
     // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
     // 2*lane+2): the two end pixels are 8-byte reads, the ten in between five 16-byte reads.  Only what is
@@ -373,9 +447,11 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     load_ab(ring[0]);
     fold_ab();
 
-    int cur = 0;
-#pragma unroll 1
-    for (int64_t r = r_begin; r < r_end; ++r) {
+    // One source row.  `cur` (the LDS slot holding row r) is a compile-time constant: the loop below is unrolled
+    // over the two slots by hand, which makes every LDS address an immediate offset and lets the newest ring
+    // entry of each stream alternate between two registers instead of being copied into place.
+    auto row = [&](const int r, auto slot) {
+        constexpr int cur = decltype(slot)::value;
         // One wave == one workgroup: wave_sync() only orders LDS accesses for the compiler.
         // LDS latency schedule of one row.  The compiler emits a full s_waitcnt lgkmcnt(0) drain whenever it
         // cannot count (more than 15 operations in flight, or at the loop header), so requests and first uses
@@ -396,7 +472,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         // Whole 16-byte reads where registers allow: 8-byte reads at this 16-byte lane stride are 2-way bank
         // conflicts, but the three unused end entries of the wide form must be kept alive until their planes
         // are consumed (see load_ab), and the map variant has no registers to spare (260 -> 1 wave/SIMD).
-        constexpr bool WIDE_ENDS = !MAP;
+        constexpr bool WIDE_ENDS = true;
         if constexpr (WIDE_ENDS) {
 #pragma unroll
             for (int t = 0; t < 7; ++t) {
@@ -447,6 +523,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         load_ab(ring[cur ^ 1]);
         // (6) the ab stream
         __builtin_amdgcn_sched_barrier(0);
+        const Px2 head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
             if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
@@ -458,17 +535,21 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         // Branch-free on purpose: a conditional epilogue splits the loop body into basic blocks, the
         // compiler then sinks most of the blur below the branch and the scheduling fences above lose
         // their meaning.  During the 10 warm-up rows of a strip the values are computed and discarded.
-        const int64_t y = r - 5;
-        const bool row_ok = y >= y0;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int64_t x = x0 + 2 * lane + c;
-            const bool ok = row_ok && x < W;
-            const float v = ssim_px(accAB[c][0].x, accAB[c][0].y, accQ[c][0].x, accQ[c][0].y, c == 0 ? accX[0].x : accX[0].y, args.c1, args.c2);
-            colsum += ok ? (double)v : 0.0;         // fp64 accumulation, src/ssim_avx.cpp:357-358
-            if constexpr (MAP) {
-                if (ok) ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = v;
-            }
+        const int y = r - 5;
+        const bool row_ok = y >= y0 && y < y_end;   // y == y_end: the padding row of an odd-length strip
+        const f2 v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
+        // fp64 accumulation, src/ssim_avx.cpp:357-358
+        colsum += (double)((row_ok && col_ok[0]) ? v.x : 0.0f);
+        colsum += (double)((row_ok && col_ok[1]) ? v.y : 0.0f);
+        if constexpr (MAP) {
+            // Branch-free store: a raw buffer descriptor over [row base, +2 GiB); lanes with nothing to store
+            // present an offset beyond it and the hardware drops the write.  (Conditional stores would split
+            // the loop body into basic blocks and void the scheduling fences above.)
+            float* mrow = pd.map + ((int64_t)y * pd.map_stride + (int64_t)refM * pd.map_step);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mrow, 0, 0x7FFFFFFF, 0x00020000);
+            const float v0 = v.x, v1 = v.y;     // (bit_cast straight from a vector element reads element 0 for both)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), rs, (row_ok && col_ok[0]) ? offM[0] : 0x80000000u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), rs, (row_ok && col_ok[1]) ? offM[1] : 0x80000000u, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -478,7 +559,11 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         stage(ring[cur]);                           // row r+2 replaces row r
         fetch(r + 3);
         wave_sync();
-        cur ^= 1;
+    };
+#pragma unroll 1
+    for (int r = r_begin; r < r_end; r += 2) {
+        row(r, std::integral_constant<int, 0>());
+        row(r + 1, std::integral_constant<int, 1>());
     }
     strip_finish(args, st, colsum);
 }
@@ -735,12 +820,17 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     if (strip_rows <= 0) {
         // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per
-        // SIMD on every CU: aim for >= 8 strips per CU over the whole batch.  Then even the strips
-        // out (1080 rows -> 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
-        const uint64_t want = (uint64_t)(cu_count > 0 ? cu_count : 256) * 8;
-        uint32_t rows = 256;
-        while (rows > 32 && (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count < want)
-            rows >>= 1;
+        // SIMD on every CU: aim for >= 8 strips per CU over the whole batch (512-row strips only when
+        // that still leaves >= 32 per CU: measured +1.5 % on 32 x 4096^2, a loss with fewer).  Then even
+        // the strips out (1080 rows -> 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
+        const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256);
+        auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count; };
+        uint32_t rows = 512;
+        if (strips(rows) < cus * 32) {
+            rows = 256;
+            while (rows > 32 && strips(rows) < cus * 8)
+                rows >>= 1;
+        }
         const uint32_t ny = height ? (height + rows - 1) / rows : 1;
         strip_rows = (int)(height ? (height + ny - 1) / ny : rows);
     }

@@ -13,7 +13,7 @@ def main():
     want = sys.argv[2:]
     starts = [(m.start(), m.group(1)) for m in re.finditer(r'^(_ZN8ssim_hip\S*):', s, re.M)]
     for idx, (pos, name) in enumerate(starts):
-        if 'strip_kernel' not in name:
+        if 'strip' not in name or 'kernel' not in name:
             continue
         if want and not any(w in name for w in want):
             continue

@@ -2,7 +2,7 @@
 """Minimal torch-free workload for rocprofv3 counter passes: the bench.py batch (N distinct 4096^2
 pairs resident in HBM, global SSIM only, or with the map) enqueued K times through the C ABI.
 
-usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [size=4096]
+usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width]
 """
 import os
 import sys
@@ -17,22 +17,23 @@ from ssim_amd import synth  # noqa: E402
 
 def main():
     arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
-    pairs, steps, mode, want_map, size = arg(1, 8), arg(2, 5), arg(3, 0), arg(4, 0), arg(5, 4096)
+    pairs, steps, mode, want_map, w = arg(1, 8), arg(2, 5), arg(3, 0), arg(4, 0), arg(5, 4096)
+    h = arg(6, w)
     ctx = ssim_amd.Context(0, mode=mode)
     params = (ssim_amd.Params * pairs)()
     keep = []
     for i in range(pairs):
-        a, b = synth.pair_numpy(size, size, synth.BASE_SEED + i)
+        a, b = synth.pair_numpy(w, h, synth.BASE_SEED + i)
         da, db = ctx.upload(a), ctx.upload(b)
-        dm = ctx.alloc(4 * size * size) if want_map else None
+        dm = ctx.alloc(4 * w * h) if want_map else None
         keep += [da, db, dm]
-        params[i] = ssim_amd.make_params(size, size, da.ptr, 1, size, db.ptr, 1, size, dm.ptr if dm else None, 1, size)
+        params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr if dm else None, 1, w)
     sums = ctx.alloc(8 * pairs)
     for _ in range(steps):
         ctx.enqueue_batch(params, pairs, sums.ptr)
     ctx.synchronize()
-    res = ssim_amd.finalize(sums.download(np.float64, (pairs,)), size, size)
-    print("pairs %d steps %d mode %d map %d size %d: ssim[0] = %.9f (0x%08x)" % (pairs, steps, mode, want_map, size, res[0], res[0].view(np.uint32)))
+    res = ssim_amd.finalize(sums.download(np.float64, (pairs,)), w, h)
+    print("pairs %d steps %d mode %d map %d size %dx%d: ssim[0] = %.9f (0x%08x)" % (pairs, steps, mode, want_map, w, h, res[0], res[0].view(np.uint32)))
     ctx.close()
 
 
