@@ -320,6 +320,8 @@ struct Slot2 {
     f2 xx[ROW_PX];   // (ab[p], ab[p+1])
 };
 
+enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
+
 template <int MODE, bool MAP>
 __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 {
@@ -396,9 +398,9 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     for (int k = 0; k < 11; ++k) {
         accAB[0][k] = accAB[1][k] = accQ[0][k] = accQ[1][k] = accX[k] = f2{0.0f, 0.0f};
     }
-    double colsum = 0.0;
+    double colsum[2] = {0.0, 0.0};
 
-    const int r_begin = y0 - 5, r_end = y_end + 5;
+    const int r_begin = y0 - 5;
     fetch(r_begin);
     stage(ring[0]);
     fetch(r_begin + 1);
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     for (int c = 0; c < 2; ++c) {
         const int x = x0 + 2 * lane + c;
         col_ok[c] = x < W;
-        if constexpr (MAP) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0u;
+        if constexpr (MAP) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0x80000000u;
     }
 
     // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
@@ -447,11 +449,14 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     load_ab(ring[0]);
     fold_ab();
 
-    // One source row.  `cur` (the LDS slot holding row r) is a compile-time constant: the loop below is unrolled
+    // One source row.  `cur` (the LDS slot holding row r) is a compile-time constant: the loops below are unrolled
     // over the two slots by hand, which makes every LDS address an immediate offset and lets the newest ring
     // entry of each stream alternate between two registers instead of being copied into place.
-    auto row = [&](const int r, auto slot) {
+    // `phase`: ROW_WARMUP = one of the 10 rows above the strip's first output row (blur only, nothing finished
+    // yet), ROW_MAIN = blur + output row r-5, ROW_LAST = ROW_MAIN without preparing any further row.
+    auto row = [&](const int r, auto slot, auto phase_tag) {
         constexpr int cur = decltype(slot)::value;
+        constexpr int phase = decltype(phase_tag)::value;
         // One wave == one workgroup: wave_sync() only orders LDS accesses for the compiler.
         // LDS latency schedule of one row.  The compiler emits a full s_waitcnt lgkmcnt(0) drain whenever it
         // cannot count (more than 15 operations in flight, or at the loop header), so requests and first uses
@@ -520,10 +525,12 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
         //     with more than 15 LDS operations in flight the compiler can only drain them all.
         __builtin_amdgcn_sched_barrier(0);
-        load_ab(ring[cur ^ 1]);
+        if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
         // (6) the ab stream
         __builtin_amdgcn_sched_barrier(0);
-        const Px2 head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
+        Px2 head;
+        if constexpr (phase != ROW_WARMUP)
+            head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
             if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
@@ -532,40 +539,54 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- ring entry 0 is now the finished output row y = r - 5 (sum_tile) ----
-        // Branch-free on purpose: a conditional epilogue splits the loop body into basic blocks, the
-        // compiler then sinks most of the blur below the branch and the scheduling fences above lose
-        // their meaning.  During the 10 warm-up rows of a strip the values are computed and discarded.
-        const int y = r - 5;
-        const bool row_ok = y >= y0 && y < y_end;   // y == y_end: the padding row of an odd-length strip
-        const f2 v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
-        // fp64 accumulation, src/ssim_avx.cpp:357-358
-        colsum += (double)((row_ok && col_ok[0]) ? v.x : 0.0f);
-        colsum += (double)((row_ok && col_ok[1]) ? v.y : 0.0f);
-        if constexpr (MAP) {
-            // Branch-free store: a raw buffer descriptor over [row base, +2 GiB); lanes with nothing to store
-            // present an offset beyond it and the hardware drops the write.  (Conditional stores would split
-            // the loop body into basic blocks and void the scheduling fences above.)
-            float* mrow = pd.map + ((int64_t)y * pd.map_stride + (int64_t)refM * pd.map_step);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mrow, 0, 0x7FFFFFFF, 0x00020000);
-            const float v0 = v.x, v1 = v.y;     // (bit_cast straight from a vector element reads element 0 for both)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), rs, (row_ok && col_ok[0]) ? offM[0] : 0x80000000u, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), rs, (row_ok && col_ok[1]) ? offM[1] : 0x80000000u, 0, 0);
+        // No per-row or per-column conditions in here: a conditional epilogue splits the loop body into basic
+        // blocks (the compiler then sinks most of the blur below the branch and the scheduling fences lose their
+        // meaning), and selects are VALU work.  Rows are sorted into phases by the loops below; columns beyond
+        // the image are computed like any other, dropped from the sum at the end and given an out-of-range
+        // map offset up front.
+        if constexpr (phase != ROW_WARMUP) {
+            const f2 v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
+            colsum[0] += (double)v.x;               // fp64 accumulation, src/ssim_avx.cpp:357-358
+            colsum[1] += (double)v.y;
+            if constexpr (MAP) {
+                // Branch-free store: a raw buffer descriptor over [row base, +2 GiB); lanes with nothing to
+                // store present an offset beyond it and the hardware drops the write.
+                const int y = r - 5;
+                float* mrow = pd.map + ((int64_t)y * pd.map_stride + (int64_t)refM * pd.map_step);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mrow, 0, 0x7FFFFFFF, 0x00020000);
+                const float v0 = v.x, v1 = v.y;     // (bit_cast straight from a vector element reads element 0 for both)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), rs, offM[0], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), rs, offM[1], 0, 0);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fold_ab();                                  // row r+1 (window requested in step (4))
-        __builtin_amdgcn_sched_barrier(0);
-        wave_sync();
-        stage(ring[cur]);                           // row r+2 replaces row r
-        fetch(r + 3);
-        wave_sync();
+        if constexpr (phase != ROW_LAST) {
+            __builtin_amdgcn_sched_barrier(0);
+            fold_ab();                                  // row r+1 (window requested in step (5))
+            __builtin_amdgcn_sched_barrier(0);
+            wave_sync();
+            stage(ring[cur]);                           // row r+2 replaces row r
+            fetch(r + 3);
+            wave_sync();
+        }
     };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    int r = r_begin;
 #pragma unroll 1
-    for (int r = r_begin; r < r_end; r += 2) {
-        row(r, std::integral_constant<int, 0>());
-        row(r + 1, std::integral_constant<int, 1>());
+    for (int i = 0; i < 5; ++i, r += 2) {
+        row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
+        row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    strip_finish(args, st, colsum);
+    const int n_out = y_end - y0;
+#pragma unroll 1
+    for (int i = n_out >> 1; i > 0; --i, r += 2) {
+        row(r, S0(), std::integral_constant<int, ROW_MAIN>());
+        row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+    }
+    if (n_out & 1)
+        row(r, S0(), std::integral_constant<int, ROW_LAST>());
+    strip_finish(args, st, (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0));
 }
 
 // ---------------------------------------------------------------------------------------------

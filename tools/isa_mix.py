@@ -24,30 +24,33 @@ def main():
             m = re.match(r'^(\.LBB\d+_\d+):', l)
             if m:
                 lab[m.group(1)] = i
-        # hot loop = the shortest backward-branch span holding >= 90% of the function's FMAs
+        # every loop (backward-branch span) with a substantial share of the function's FMAs, innermost first
         isfma = [1 if re.match(r'\s*v_(pk_)?fma(c)?_f(32|64)', l) else 0 for l in lines]
-        total = sum(isfma)
-        best = None
+        total = max(sum(isfma), 1)
+        spans = []
         for i, l in enumerate(lines):
             m = re.search(r's_c?branch\w*\s+(\.LBB\d+_\d+)', l)
             if m and m.group(1) in lab and lab[m.group(1)] < i:
                 span = (lab[m.group(1)], i)
-                if sum(isfma[span[0]:span[1]]) >= 0.9 * total and (best is None or span[1] - span[0] < best[1] - best[0]):
-                    best = span
-        body = lines[best[0]:best[1] + 1] if best else lines
-        c = collections.Counter()
-        for l in body:
-            l = l.strip()
-            if not l or l[0] in ';.' or l.endswith(':'):
-                continue
-            c[l.split()[0]] += 1
-        valu = sum(v for k, v in c.items() if k.startswith('v_'))
-        print('%s\n  loop instrs %d  VALU %d  (pk %d)  DS %d  VMEM %d  SALU %d  waitcnt %d' % (
-            name, sum(c.values()), valu, sum(v for k, v in c.items() if k.startswith('v_pk_')),
-            sum(v for k, v in c.items() if k.startswith('ds_')),
-            sum(v for k, v in c.items() if k.startswith(('global_', 'buffer_', 'flat_'))),
-            sum(v for k, v in c.items() if k.startswith('s_') and not k.startswith('s_waitcnt')), c['s_waitcnt']))
-        print('   ' + '  '.join('%s:%d' % kv for kv in c.most_common(45)))
+                if sum(isfma[span[0]:span[1]]) >= 0.1 * total:
+                    spans.append(span)
+        spans = [sp for sp in spans if not any(o != sp and sp[0] <= o[0] and o[1] <= sp[1] for o in spans)] or [(0, len(lines) - 1)]
+        print(name)
+        for span in spans:
+            body = lines[span[0]:span[1] + 1]
+            c = collections.Counter()
+            for l in body:
+                l = l.strip()
+                if not l or l[0] in ';.' or l.endswith(':'):
+                    continue
+                c[l.split()[0]] += 1
+            valu = sum(v for k, v in c.items() if k.startswith('v_'))
+            print('  loop @%d: instrs %d  VALU %d  (pk %d)  DS %d  VMEM %d  SALU %d  waitcnt %d' % (
+                span[0], sum(c.values()), valu, sum(v for k, v in c.items() if k.startswith('v_pk_')),
+                sum(v for k, v in c.items() if k.startswith('ds_')),
+                sum(v for k, v in c.items() if k.startswith(('global_', 'buffer_', 'flat_'))),
+                sum(v for k, v in c.items() if k.startswith('s_') and not k.startswith('s_waitcnt')), c['s_waitcnt']))
+            print('     ' + '  '.join('%s:%d' % kv for kv in c.most_common(45)))
 
 
 if __name__ == '__main__':
