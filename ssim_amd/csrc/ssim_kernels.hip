@@ -237,6 +237,7 @@ struct KArgs {
     PairDesc        single;       // used when descs == nullptr
     const PairDesc* descs;
     uint32_t        width, height, strip_rows, strips_x, strips_y;
+    uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     double*         partials;     // [image][strip_y][strip_x]
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
@@ -257,30 +258,40 @@ __device__ __forceinline__ void wave_sync()
 struct Strip {
     PairDesc pd;                 // wave-uniform (SGPRs)
     int64_t  W, H, x0, y0, y_end;
-    uint32_t sx, sy;
+    uint32_t sx, sy, img;
 };
 
 __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
 {
     Strip st;
-    // XCD-aware strip order.  The dispatcher hands consecutive workgroup ids to the 8 XCDs round
-    // robin; left to itself that puts horizontally adjacent strips -- which share their 2 x 8 halo
-    // columns and hence cache lines -- on different L2s (measured: 3.07x the algorithmic HBM reads).
-    // Give each XCD a contiguous run of (strip_x, strip_y) instead: 1.07x.  Speed only; correctness
-    // does not depend on placement.
-    st.sx = blockIdx.x; st.sy = blockIdx.y;
+    // XCD-aware strip order.  The dispatcher hands consecutive workgroup ids (x fastest, then y, then z) to the
+    // 8 XCDs round robin; left to itself that puts horizontally adjacent strips -- which share their 2 x 8 halo
+    // columns and hence cache lines -- on different L2s (measured: 3.07x the algorithmic HBM reads).  Renumber
+    // so that each XCD walks one contiguous eighth of the batch's strip list (image-major, then strip row, then
+    // strip column): 1.07x.  A bijection for any strip count; speed only, correctness does not depend on it.
     const uint32_t per_img = args.strips_x * args.strips_y;
     if ((per_img & 7u) == 0) {
+        // the common case needs no division by per_img: every image's strip list splits into eighths
         const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
         const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
+        st.img = blockIdx.z;
         st.sy = swz / args.strips_x;
         st.sx = swz - st.sy * args.strips_x;
+    } else {
+        const uint32_t total = per_img * args.count;
+        const uint32_t g = (blockIdx.z * args.strips_y + blockIdx.y) * args.strips_x + blockIdx.x;
+        const uint32_t xcd = g & 7u, slot = g >> 3, q = total >> 3, rem = total & 7u;
+        const uint32_t id = xcd * q + (xcd < rem ? xcd : rem) + slot;  // XCD k owns q (+1 for the first `rem`) strips
+        st.img = id / per_img;
+        const uint32_t lin = id - st.img * per_img;
+        st.sy = lin / args.strips_x;
+        st.sx = lin - st.sy * args.strips_x;
     }
     // Everything in the descriptor is wave-uniform: keep it in SGPRs so that row addressing is
     // scalar arithmetic (a descriptor fetched through a pointer would otherwise sit in VGPRs).
     st.pd = args.single;
     if (args.descs) {
-        const gptr_desc gd = (gptr_desc)args.descs + blockIdx.z;
+        const gptr_desc gd = (gptr_desc)args.descs + st.img;
         st.pd.a = (const uint8_t*)uniform64((int64_t)gd->a); st.pd.a_step = uniform64(gd->a_step); st.pd.a_stride = uniform64(gd->a_stride);
         st.pd.b = (const uint8_t*)uniform64((int64_t)gd->b); st.pd.b_step = uniform64(gd->b_step); st.pd.b_stride = uniform64(gd->b_stride);
         st.pd.map = (float*)uniform64((int64_t)gd->map); st.pd.map_step = uniform64(gd->map_step); st.pd.map_stride = uniform64(gd->map_stride);
@@ -299,7 +310,7 @@ __device__ __forceinline__ void strip_finish(const KArgs& args, const Strip& st,
     for (int off = 32; off > 0; off >>= 1)
         tot += __shfl_down(tot, off, 64);
     if (threadIdx.x == 0)
-        ((gptr_f64)args.partials)[((size_t)blockIdx.z * args.strips_y + st.sy) * args.strips_x + st.sx] = tot;
+        ((gptr_f64)args.partials)[((size_t)st.img * args.strips_y + st.sy) * args.strips_x + st.sx] = tot;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -870,6 +881,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* de
     ka.descs = descs_dev;
     ka.width = geo.width; ka.height = geo.height;
     ka.strip_rows = geo.strip_rows; ka.strips_x = geo.strips_x; ka.strips_y = geo.strips_y;
+    ka.count = geo.count;
     ka.partials = partials;
     // c1, c2: products in double, then cast (src/ssim.cpp:956-960)
     ka.c1d = (0.01 * 255.0) * (0.01 * 255.0);

@@ -160,6 +160,60 @@ def test_interleaved_bottom_up_and_column_major_addressing(gpu_ctx, manifest):
             d.free()
 
 
+@pytest.mark.parametrize("mode", [ssim_amd.MODE_EXACT, ssim_amd.MODE_FAST])
+def test_mirrored_storage_and_far_apart_pixels(gpu_ctx, oracle, mode):
+    """Negative pixel steps (images and map stored right-to-left, several strips wide) and steps too large for
+    the two-column kernel's 32-bit lane offsets (fits_strip2() false -> the 64-bit one-column kernel)."""
+    gpu_ctx.set_mode(mode)
+    rng = np.random.default_rng(1234)
+    keep = []
+    try:
+        h, w = 37, 301
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)
+        want_v, want_m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        if mode == ssim_amd.MODE_EXACT:
+            ov, _, om = oracle.ssim_f32(a, b, want_map=True)
+            assert_same_map(want_m, om, "plain")
+        am, bm = np.ascontiguousarray(a[:, ::-1]), np.ascontiguousarray(b[:, ::-1])
+        # A mirrored (step -1), B plain, map mirrored (step -1) and bottom-up (stride -w)
+        p, dm = device_params(gpu_ctx, keep, am, w - 1, -1, w, b, 0, 1, w, w, h,
+                              map_floats=w * h, map_off=(h - 1) * w + (w - 1), map_step=-1, map_stride=-w)
+        v = gpu_ctx.compute_device(p)
+        assert f32_hex(v) == f32_hex(want_v)
+        assert_same_map(np.ascontiguousarray(dm.download(np.float32, (h, w))[::-1, ::-1]), want_m, "mirrored")
+        # both mirrored with a step of -2 inside double-width rows
+        a2 = np.zeros((h, 2 * w), np.uint8); a2[:, 0::2] = am
+        b2 = np.zeros((h, 2 * w), np.uint8); b2[:, 1::2] = bm
+        p, dm = device_params(gpu_ctx, keep, a2, 2 * (w - 1), -2, 2 * w, b2, 2 * (w - 1) + 1, -2, 2 * w, w, h, map_floats=w * h, map_step=1, map_stride=w)
+        v = gpu_ctx.compute_device(p)
+        assert f32_hex(v) == f32_hex(want_v)
+        assert_same_map(dm.download(np.float32, (h, w)), want_m, "step -2")
+
+        # pixels 2 MiB apart, rows 7 bytes apart (overlapping rows are legal: the library only reads)
+        h, w, step, stride = 9, 6, (1 << 21) + 3, 7
+        n = (w - 1) * step + (h - 1) * stride + 1
+        bufa = rng.integers(0, 256, n, dtype=np.uint8)
+        bufb = rng.integers(0, 256, n, dtype=np.uint8)
+        idx = (np.arange(h)[:, None] * stride + np.arange(w)[None, :] * step)
+        a, b = bufa[idx], bufb[idx]
+        mstep = 1 << 21
+        p, dm = device_params(gpu_ctx, keep, bufa, 0, step, stride, bufb, 0, step, stride, w, h,
+                              map_floats=(w - 1) * mstep + (h - 1) * 5 + 1, map_step=mstep, map_stride=5)
+        v = gpu_ctx.compute_device(p)
+        ref_v, ref_m = gpu_ctx.ssim_planes(a, b, want_map=True)
+        assert f32_hex(v) == f32_hex(ref_v)
+        got = dm.download(np.float32, ((w - 1) * mstep + (h - 1) * 5 + 1,))[(np.arange(h)[:, None] * 5 + np.arange(w)[None, :] * mstep)]
+        assert_same_map(np.ascontiguousarray(got), ref_m, "far apart")
+        if mode == ssim_amd.MODE_EXACT:
+            ov, _, om = oracle.ssim_f32(a, b, want_map=True)
+            assert_same_map(ref_m, om, "far apart vs oracle")
+    finally:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+        for d in keep:
+            d.free()
+
+
 def test_dropin_host_entry_points(gpu_ctx, manifest, lib):
     """rmgr_ssim_compute_ssim / _openmp on HOST pointers (the unchanged reference call), incl. map
     with ssimStep != 1, map-only, global-only, user allocator, and allocator failure -> ENOMEM."""

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the bench lines, the rocprofv3 kernel trace of the bench command and the
+# PMC passes (one rocprofv3 run per counter set, torch-free target) that profiles/ summarises.
+# usage: tools/collect_profiles.sh <out-subdir-of-gpurun_out>
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/${1:-prof_final}
+rm -rf "$OUT"; mkdir -p "$OUT"
+export TMPDIR=/tmp
+for wl in 4k 8k-map 1080p; do
+  timeout 600 python3 bench.py --workload $wl > "$OUT/bench_$wl.log" 2>&1
+  grep '"metric"' "$OUT/bench_$wl.log" > "$OUT/bench_$wl.json"
+done
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+grep '"metric"' "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json"
+pmc() {   # name, counters, target args...
+  local name=$1 ctrs=$2; shift 2
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
+}
+for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096"; do
+  set -- $cfg; tag=$1; shift
+  pmc ${tag}_fetch FETCH_SIZE "$@"
+  pmc ${tag}_write WRITE_SIZE "$@"
+  pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
+  pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
+done
+find "$OUT" -name "*.csv" | head -50
+du -sh "$OUT"
