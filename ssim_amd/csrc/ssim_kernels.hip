@@ -137,6 +137,27 @@ __device__ __forceinline__ void blur_exact(V (&acc)[11], V s0, V s1, V s2, V s3,
     acc[10] = S5;
 }
 
+// acc[k] = h * g + acc[k+1]: the ring step of the separable blur.  In fp32 the packed FMA only exists in
+// three-address form, which is what makes the ring shift free.  For fp64 the compiler prefers the two-address
+// v_fmac_f64 (in place over acc[k+1]) and then copies every entry back into its loop-carried register -- one
+// v_mov_b64 per FMA; spelling the three-address instruction out avoids that.  (Plain VALU-to-VALU dependency:
+// interlocked by the hardware, nothing here for the hazard recogniser to miss.)
+__device__ __forceinline__ f2 ring_fma(f2 h, float g, f2 c)   { return fma_(h, f2{g, g}, c); }
+__device__ __forceinline__ float ring_fma(float h, float g, float c) { return fma_(h, g, c); }
+__device__ __forceinline__ double ring_fma(double h, double g, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(h), "s"(g), "v"(c));
+    return d;
+}
+__device__ __forceinline__ d2 ring_fma(d2 h, double g, d2 c)
+{
+    d2 d;
+    d.x = ring_fma(h.x, g, c.x);
+    d.y = ring_fma(h.y, g, c.y);
+    return d;
+}
+
 // Separable blur (MODE_FAST fp32 / MODE_DOUBLE fp64): 1-D pass along the row on the folded
 // sums, then the vertical pass as the same ring scatter.  g[] = centre..edge taps of the true
 // 1-D Gaussian (g(x)g(y) equals the 2-D kernel of tests/ssim_naive.h to 7e-18).
@@ -149,16 +170,16 @@ __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V
     h = fma_(s3, VT<V>::splat(g[3]), h);
     h = fma_(s4, VT<V>::splat(g[4]), h);
     h = fma_(s5, VT<V>::splat(g[5]), h);
-    acc[0] = fma_(h, VT<V>::splat(g[5]), acc[1]);
-    acc[1] = fma_(h, VT<V>::splat(g[4]), acc[2]);
-    acc[2] = fma_(h, VT<V>::splat(g[3]), acc[3]);
-    acc[3] = fma_(h, VT<V>::splat(g[2]), acc[4]);
-    acc[4] = fma_(h, VT<V>::splat(g[1]), acc[5]);
-    acc[5] = fma_(h, VT<V>::splat(g[0]), acc[6]);
-    acc[6] = fma_(h, VT<V>::splat(g[1]), acc[7]);
-    acc[7] = fma_(h, VT<V>::splat(g[2]), acc[8]);
-    acc[8] = fma_(h, VT<V>::splat(g[3]), acc[9]);
-    acc[9] = fma_(h, VT<V>::splat(g[4]), acc[10]);
+    acc[0] = ring_fma(h, g[5], acc[1]);
+    acc[1] = ring_fma(h, g[4], acc[2]);
+    acc[2] = ring_fma(h, g[3], acc[3]);
+    acc[3] = ring_fma(h, g[2], acc[4]);
+    acc[4] = ring_fma(h, g[1], acc[5]);
+    acc[5] = ring_fma(h, g[0], acc[6]);
+    acc[6] = ring_fma(h, g[1], acc[7]);
+    acc[7] = ring_fma(h, g[2], acc[8]);
+    acc[8] = ring_fma(h, g[3], acc[9]);
+    acc[9] = ring_fma(h, g[4], acc[10]);
     acc[10] = h * VT<V>::splat(g[5]);
 }
 
@@ -601,10 +622,14 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 }
 
 // ---------------------------------------------------------------------------------------------
-// ssim_strip1_kernel -- one column per lane, 64-column strips.  Half the accumulator registers
-// (4 waves/SIMD in fp32), more loader/LDS work per pixel: measured 10-14 % slower than the
-// two-column kernel in the fp32 modes (kept as tuning variant 1), and the only shape whose fp64
-// accumulators (110 VGPRs) fit: MODE_DOUBLE always runs here.  The ab plane is a scalar stream.
+// ssim_strip1_kernel -- one column per lane, 64-column strips; the same row choreography as the
+// two-column kernel (two LDS slots unrolled by hand, warm-up / main / last phases, the next row's
+// (a,b) window requested a stream ahead and folded at the bottom of the iteration).  Two jobs:
+//  * MODE_DOUBLE: the only shape whose fp64 accumulator rings (110 VGPRs) fit in the register file;
+//  * the fully general fallback of the fp32 modes: 64-bit coordinates and per-lane 64-bit offsets
+//    (image pairs fits_strip2() rejects) and tuning variant 1.  In fp32 it has half the accumulator
+//    registers of the two-column kernel but twice the loader/LDS work per pixel: 10-14 % slower.
+// The ab plane is a scalar stream here.
 // ---------------------------------------------------------------------------------------------
 struct Slot1 {
     static constexpr int STRIP_W = 64, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
@@ -674,53 +699,65 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         accX[k] = VT<XV>::splat(0);
     }
     double colsum = 0.0;
+    const int64_t xcol = x0 + lane;
+    const bool col_ok = xcol < W;
+    const int64_t map_off = MAP ? xcol * pd.map_step : 0;
 
-    const int64_t r_begin = y0 - 5, r_end = y_end + 5;
+    const int64_t r_begin = y0 - 5;
     fetch(r_begin);
     stage(ring[0]);
     fetch(r_begin + 1);
-    int cur = 0;
+    stage(ring[1]);
+    fetch(r_begin + 2);
+    wave_sync();
 
-#pragma unroll 1
-    for (int64_t r = r_begin; r < r_end; ++r) {
-        // Software pipeline: row r+1 goes to the other slot, row r+2 is requested from memory,
-        // then row r is consumed.
-        stage(ring[cur ^ 1]);
-        fetch(r + 2);
-        wave_sync();
+    // Window of the lane's column: slot pixels base .. base+10 (centre base+5).
+    const int base = lane + PAD - 5;
+    f2 wab[11], wq[11];
+    float wx[11];
+    // folded (a,b) sums of the row about to be blurred + its centre pixel, carried over the loop edge
+    f2 fa[5], ca;
+    auto load_ab = [&](const Slot1& s) {
+#pragma unroll
+        for (int t = 0; t < 11; ++t) wab[t] = s.ab[base + t];
+    };
+    auto fold_ab = [&]() {
+        ca = wab[5];
+#pragma unroll
+        for (int i = 1; i <= 5; ++i) fa[i - 1] = wab[5 + i] + wab[5 - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
+    };
+    load_ab(ring[0]);
+    fold_ab();
+
+    auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5) {
+        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
+        else if constexpr (MODE == MODE_FAST)                     blur_separable(acc, s0, s1, s2, s3, s4, s5, args.gf);
+        else  // fp64 internals: the folded sums are exact integers in fp32; everything after is double
+            blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
+    };
+
+    auto row = [&](const int64_t r, auto slot, auto phase_tag) {
+        constexpr int cur = decltype(slot)::value;
+        constexpr int phase = decltype(phase_tag)::value;
         const Slot1& s = ring[cur];
         __builtin_amdgcn_s_setprio(2);               // see ssim_strip2_kernel
-
-        f2 wab[11], wq[11];
-        float wx[11];
-        const int base = lane + PAD - 5;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
-            wab[t] = s.ab[base + t];
             wq[t] = s.q[base + t];
             wx[t] = s.x[base + t];
         }
-        const f2 a1 = wab[6] + wab[4], a2 = wab[7] + wab[3], a3 = wab[8] + wab[2], a4 = wab[9] + wab[1], a5 = wab[10] + wab[0];
-        const f2 q1 = wq[6] + wq[4], q2 = wq[7] + wq[3], q3 = wq[8] + wq[2], q4 = wq[9] + wq[1], q5 = wq[10] + wq[0];
-        const float x1 = wx[6] + wx[4], x2 = wx[7] + wx[3], x3 = wx[8] + wx[2], x4 = wx[9] + wx[1], x5 = wx[10] + wx[0];
-        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
-            blur_exact<FUSED>(accAB, wab[5], a1, a2, a3, a4, a5);
-            blur_exact<FUSED>(accQ, wq[5], q1, q2, q3, q4, q5);
-            blur_exact<FUSED>(accX, wx[5], x1, x2, x3, x4, x5);
-        } else if constexpr (MODE == MODE_FAST) {
-            blur_separable(accAB, wab[5], a1, a2, a3, a4, a5, args.gf);
-            blur_separable(accQ, wq[5], q1, q2, q3, q4, q5, args.gf);
-            blur_separable(accX, wx[5], x1, x2, x3, x4, x5, args.gf);
-        } else {
-            // fp64 internals: the folded sums are exact integers in fp32; everything after is double
-            blur_separable(accAB, to_f64(wab[5]), to_f64(a1), to_f64(a2), to_f64(a3), to_f64(a4), to_f64(a5), args.gd);
-            blur_separable(accQ, to_f64(wq[5]), to_f64(q1), to_f64(q2), to_f64(q3), to_f64(q4), to_f64(q5), args.gd);
-            blur_separable(accX, to_f64(wx[5]), to_f64(x1), to_f64(x2), to_f64(x3), to_f64(x4), to_f64(x5), args.gd);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4]);
+        __builtin_amdgcn_sched_barrier(0);
+        blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0]);
+        __builtin_amdgcn_sched_barrier(0);
 
-        const int64_t y = r - 5;
-        const int64_t x = x0 + lane;
-        if (y >= y0 && x < W) {
+        if constexpr (phase != ROW_WARMUP) {         // ring entry 0 is the finished output row y = r - 5
             float vmap;
             if constexpr (DBL) {
                 const double v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1d, args.c2d);
@@ -731,14 +768,38 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
                 colsum += (double)v;
                 vmap = v;
             }
-            if constexpr (MAP)
-                ((gptr_f32)pd.map)[y * pd.map_stride + x * pd.map_step] = vmap;
+            if constexpr (MAP) {
+                if (col_ok) ((gptr_f32)pd.map)[(r - 5) * pd.map_stride + map_off] = vmap;
+            }
         }
         __builtin_amdgcn_s_setprio(0);
-        wave_sync();
-        cur ^= 1;
+        if constexpr (phase != ROW_LAST) {
+            __builtin_amdgcn_sched_barrier(0);
+            fold_ab();
+            __builtin_amdgcn_sched_barrier(0);
+            wave_sync();
+            stage(ring[cur]);                       // row r+2 replaces row r
+            fetch(r + 3);
+            wave_sync();
+        }
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    int64_t r = r_begin;
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i, r += 2) {
+        row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
+        row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    strip_finish(args, st, colsum);
+    const int64_t n_out = y_end - y0;
+#pragma unroll 1
+    for (int64_t i = n_out >> 1; i > 0; --i, r += 2) {
+        row(r, S0(), std::integral_constant<int, ROW_MAIN>());
+        row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+    }
+    if (n_out & 1)
+        row(r, S0(), std::integral_constant<int, ROW_LAST>());
+    strip_finish(args, st, col_ok ? colsum : 0.0);
 }
 
 // Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then
