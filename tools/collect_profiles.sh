@@ -23,5 +23,13 @@ for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920
   pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
   pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
 done
-find "$OUT" -name "*.csv" | head -50
+# kernel-only speeds per mode (HIP events, tools/ab.py): batch of 8, single pair, with map
+{
+  for m in 0 3 1 2; do timeout 300 python3 tools/ab.py 8 4096 $m 0 0 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode $m:/"; done
+  for m in 0 1 2; do timeout 300 python3 tools/ab.py 1 4096 $m 0 0 3 0 | tail -1 | sed "s/^/1 x 4096^2 mode $m:/"; done
+  for m in 0 1 2; do timeout 300 python3 tools/ab.py 2 8192 $m 0 0 3 1 | tail -1 | sed "s/^/2 x 8192^2 + map mode $m:/"; done
+  timeout 300 python3 tools/ab.py 8 4096 0 0 1 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode 0 one-column kernel:/"
+} > "$OUT/mode_speeds.txt" 2>&1
+timeout 900 python3 tests/tools/error_table.py > "$OUT/error_table.md" 2> "$OUT/error_table.err"
+find "$OUT" -name "*.csv" | wc -l
 du -sh "$OUT"
