@@ -56,6 +56,18 @@ rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32
  * kernel variant.  Results do not depend on either (tests/test_gpu_parity.py checks). */
 rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT;
 
+/* How a launch of `count` width x height pairs is cut into wavefront strips under the context's mode and
+ * tuning (ctx may be NULL: default mode, default tuning, a 256-CU device).  Pure host arithmetic: no device
+ * is touched.  The reference's counterpart is its 256x64 tile grid (src/ssim.cpp:1026-1028). */
+typedef struct rmgr_ssim_hip_Plan
+{
+    rmgr_uint32_t stripWidth;        /* output columns per wavefront: 128 (two per lane) or 64 */
+    rmgr_uint32_t stripRows;         /* output rows per wavefront */
+    rmgr_uint32_t stripsX, stripsY;  /* strips per image */
+    rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count = workgroups of the launch */
+} rmgr_ssim_hip_Plan;
+rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT;
+
 /*
  * compute_ssim() on HOST pointers: stages both images to HBM, runs the kernels, copies the map
  * back (any ssimStep/ssimStride), returns the global SSIM.  Validation and return codes are the

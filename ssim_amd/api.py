@@ -43,6 +43,11 @@ class Params(ctypes.Structure):
                 ("alloc", AllocFct), ("dealloc", DeallocFct)]
 
 
+class Plan(ctypes.Structure):
+    _fields_ = [("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
+                ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32)]
+
+
 class ThreadPool(ctypes.Structure):
     _fields_ = [("dispatch", ThreadPoolFct), ("context", ctypes.c_void_p), ("threadCount", ctypes.c_uint32)]
 
@@ -58,7 +63,7 @@ C_SYMBOLS = [
     "rmgr_ssim_get_version", "rmgr_ssim_init_interleaved", "rmgr_ssim_init_planar", "rmgr_ssim_use_default_allocator",
     "rmgr_ssim_compute_ssim", "rmgr_ssim_compute_ssim_openmp",
     "rmgr_ssim_hip_get_device_count", "rmgr_ssim_hip_create", "rmgr_ssim_hip_destroy", "rmgr_ssim_hip_set_mode",
-    "rmgr_ssim_hip_get_mode", "rmgr_ssim_hip_set_tuning", "rmgr_ssim_hip_compute_ssim_host",
+    "rmgr_ssim_hip_get_mode", "rmgr_ssim_hip_set_tuning", "rmgr_ssim_hip_get_plan", "rmgr_ssim_hip_compute_ssim_host",
     "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
@@ -100,6 +105,7 @@ def load_library(path=None):
         "rmgr_ssim_hip_set_mode": [vp, i32],
         "rmgr_ssim_hip_get_mode": [vp, ctypes.POINTER(i32)],
         "rmgr_ssim_hip_set_tuning": [vp, i32, i32],
+        "rmgr_ssim_hip_get_plan": [vp, u32, u32, u32, ctypes.POINTER(Plan)],
         "rmgr_ssim_hip_compute_ssim_host": [vp, ctypes.POINTER(ctypes.c_float), PP, ctypes.POINTER(ThreadPool)],
         "rmgr_ssim_hip_compute_ssim_device": [vp, ctypes.POINTER(ctypes.c_float), PP],
         "rmgr_ssim_hip_enqueue_batch": [vp, u32, PP, vp],
@@ -128,6 +134,14 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def get_plan(width, height, count=1, ctx=None):
+    """Strip geometry of a launch (include/rmgr/ssim-hip.h rmgr_ssim_hip_get_plan); needs no device when ctx is None."""
+    lib = load_library()
+    out = Plan()
+    _check("rmgr_ssim_hip_get_plan", lib.rmgr_ssim_hip_get_plan(ctx.handle if ctx is not None else None, width, height, count, ctypes.byref(out)))
+    return out
 
 
 def _check(name, rc):

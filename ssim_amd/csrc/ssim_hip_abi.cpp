@@ -316,6 +316,19 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t str
     return 0;
 }
 
+rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT
+{
+    if (!plan) return EINVAL;
+    const ssim_hip::Geometry geo = c ? ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count)
+                                     : ssim_hip::plan(width, height, count, RMGR_SSIM_HIP_MODE_EXACT, 0, 0, 256);
+    plan->stripWidth = geo.strip_w;
+    plan->stripRows = geo.strip_rows;
+    plan->stripsX = geo.strips_x;
+    plan->stripsY = geo.strips_y;
+    plan->wavefronts = geo.strips_x * geo.strips_y * count;
+    return 0;
+}
+
 rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t count, const rmgr_ssim_Params* params, double* sumsDevice) RMGR_NOEXCEPT
 {
     if (!c || (count && (!params || !sumsDevice))) return EINVAL;

@@ -190,3 +190,22 @@ def test_bench_refuses_to_run_without_the_gpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "no HIP device" in (r.stderr + r.stdout)
     assert "metric" not in r.stdout
+
+
+def test_strip_plan_covers_every_image_and_fills_the_gpu():
+    """rmgr_ssim_hip_get_plan: pure host arithmetic (no device needed with a NULL context).  The strips must
+    tile the image exactly, and the defaults are the ones DESIGN.md section 5 documents."""
+    import ssim_amd
+    for (w, h, n) in [(1, 1, 1), (7, 3, 1), (128, 64, 1), (129, 65, 2), (256, 256, 1), (1920, 1080, 128), (4096, 4096, 1),
+                      (4096, 4096, 32), (8192, 8192, 2), (65537, 3, 1), (3, 65537, 1), (255, 63, 1000)]:
+        p = ssim_amd.get_plan(w, h, n)
+        assert p.stripWidth == 128 and p.stripRows >= 1
+        assert (p.stripsX - 1) * p.stripWidth < w <= p.stripsX * p.stripWidth
+        assert (p.stripsY - 1) * p.stripRows < h <= p.stripsY * p.stripRows
+        assert p.wavefronts == p.stripsX * p.stripsY * n
+    assert ssim_amd.get_plan(1920, 1080, 128).stripRows == 216          # 5 even strips, not 4 x 256 + 56
+    assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 512           # >= 32 strips per CU left
+    assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # a single image still gets 8 waves per CU
+    assert ssim_amd.get_plan(0, 0, 1).wavefronts == 0
+    lib = ssim_amd.load_library()
+    assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL
