@@ -20,11 +20,12 @@
 //    MODE_EXACT reproduces its rounding order bit for bit -- and (d) the ring's oldest entry is
 //    a finished output row: SSIM formula, fp64 accumulation, optional map store.
 //  * Intermediates never touch HBM: algorithmic traffic is 2 B/pixel (+4 B/pixel with a map).
-//  * The kernel is fp32-VALU bound (~150 packed instructions per pixel in MODE_EXACT), not HBM
+//  * The kernel is fp32-VALU bound (~140 packed instructions per pixel in MODE_EXACT), not HBM
 //    bound; see DESIGN.md for the roofline arithmetic.
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off   (fusion only where fma is written;
-// float division stays IEEE correctly rounded: no -ffast-math anywhere).
+// float division stays IEEE correctly rounded -- div_inrange_* is the compiler's own sequence minus
+// range handling that cannot trigger here -- and there is no -ffast-math anywhere).
 #include "ssim_kernels.h"
 #include <cmath>
 #include <type_traits>
@@ -341,9 +342,10 @@ __device__ __forceinline__ void strip_finish(const KArgs& args, const Strip& st,
 // pairs xx[p] = (ab[p], ab[p+1]) so that ALL five blur streams are packed-fp32 code on naturally
 // aligned register pairs (no v_pk_mov shuffles), fed by 16-byte ds_read_b128.
 // Tried and dropped (measured on MI355X, round 1): refilling each plane's window for row r+1 right
-// after its last use (+36 VGPRs -> 1 wave/SIMD), unrolling the row loop over the two LDS slots
-// (312 registers), skipping the row sums halo rows cannot use (branches in the hot loop: -10 %),
-// forcing 3 waves/SIMD with launch bounds (spills: 5x slower).
+// after its last use (+36 VGPRs -> 1 wave/SIMD), skipping the row sums halo rows cannot use (branches
+// in the hot loop: -10 %), forcing 3 waves/SIMD with launch bounds (spills: 5x slower), a second pixel
+// row in flight from HBM (+-0), reordering the ring scatter so that the newest entry needs no copy (the
+// copy moves to the oldest entry instead; unrolling over the two LDS slots is what removes it).
 // ---------------------------------------------------------------------------------------------
 struct Slot2 {
     static constexpr int STRIP_W = 128, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
@@ -506,35 +508,17 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_s_setprio(2);
         // (1), (2) request the other two planes of this row
         __builtin_amdgcn_sched_barrier(0);
-        // Whole 16-byte reads where registers allow: 8-byte reads at this 16-byte lane stride are 2-way bank
-        // conflicts, but the three unused end entries of the wide form must be kept alive until their planes
-        // are consumed (see load_ab), and the map variant has no registers to spare (260 -> 1 wave/SIMD).
-        constexpr bool WIDE_ENDS = true;
-        if constexpr (WIDE_ENDS) {
+        // Whole 16-byte reads only: 8-byte reads at this 16-byte lane stride are 2-way bank conflicts.  The three
+        // end entries the wide form loads without need are kept alive until their planes are consumed (see load_ab).
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-            }
+        for (int t = 0; t < 7; ++t) {
+            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+        }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-                wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
-            }
-        } else {
-            wq[1] = s.q[e + 1];
-#pragma unroll
-            for (int t = 1; t < 6; ++t) {
-                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-            }
-            wq[12] = s.q[e + 12];
-            wxx[1] = s.xx[e + 1];
-#pragma unroll
-            for (int t = 1; t < 6; ++t) {
-                const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-                wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
-            }
+        for (int t = 0; t < 6; ++t) {
+            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
@@ -553,7 +537,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             if constexpr (EXACT) blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
             else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
         }
-        if constexpr (WIDE_ENDS) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
+        asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
         // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
         //     with more than 15 LDS operations in flight the compiler can only drain them all.
         __builtin_amdgcn_sched_barrier(0);
