@@ -90,3 +90,40 @@ def test_random_layouts_bit_exact(gpu_ctx, oracle):
         assert np.all(got[mask] == -3.0), case
     gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
     gpu_ctx.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("mode", [ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED])
+def test_division_corner_statistics_bit_exact(gpu_ctx, oracle, mode):
+    """The two-column kernel divides with the compiler's IEEE sequence minus v_div_scale / v_div_fixup (operands
+    are provably in range, ssim_kernels.hip div_inrange_*).  Exercise the corners of that range: anti-correlated
+    textures whose covariance sweeps 2*sAB + c2 through zero (tiny and sign-changing numerators), flat images
+    (variances exactly zero), saturated black / white, maximal contrast.  The oracle divides on the CPU."""
+    gpu_ctx.set_mode(mode)
+    rng = np.random.default_rng(4242)
+    h, w = 200, 640
+    xx = np.arange(w)[None, :].repeat(h, 0)
+    try:
+        seen_small = seen_neg = 0
+        for kk in (1.0, 0.5, 2.0, 1.0):
+            amp = xx / w * (12.0 / np.sqrt(kk))
+            t = rng.choice([-1.0, 1.0], (h, w))
+            base = int(rng.integers(60, 196))
+            a = np.clip(np.rint(base + amp * t), 0, 255).astype(np.uint8)
+            b = np.clip(np.rint(base - kk * amp * t), 0, 255).astype(np.uint8)
+            ov, _, om = oracle.ssim_f32(a, b, want_map=True, fused=(mode == ssim_amd.MODE_EXACT))
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            assert np.array_equal(m.view(np.uint32), om.view(np.uint32)), kk
+            assert ulp_diff(v, ov) <= 1
+            seen_small += int((np.abs(om) < 1e-3).sum())
+            seen_neg += int((om < 0).sum())
+        assert seen_small > 100 and seen_neg > 1000, (seen_small, seen_neg)     # the sweep really crossed zero
+        for a, b in [(np.zeros((40, 300), np.uint8), np.full((40, 300), 255, np.uint8)),
+                     (np.full((40, 300), 255, np.uint8), np.full((40, 300), 255, np.uint8)),
+                     (rng.choice([0, 255], (90, 400)).astype(np.uint8), rng.choice([0, 255], (90, 400)).astype(np.uint8)),
+                     ((np.indices((64, 256)).sum(0) % 2 * 255).astype(np.uint8), (255 - np.indices((64, 256)).sum(0) % 2 * 255).astype(np.uint8))]:
+            ov, _, om = oracle.ssim_f32(a, b, want_map=True, fused=(mode == ssim_amd.MODE_EXACT))
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            assert np.array_equal(m.view(np.uint32), om.view(np.uint32))
+            assert ulp_diff(v, ov) <= 1
+    finally:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
