@@ -126,7 +126,8 @@ int record_begin(rmgr_ssim_hip_Context* c, hipEvent_t& b, hipEvent_t& e)
         HIP_TRY(hipEventCreate(&b));
         HIP_TRY(hipEventCreate(&e));
     }
-    c->pending.push_back(std::make_pair(b, e));
+    try { c->pending.push_back(std::make_pair(b, e)); }
+    catch (...) { (void)hipEventDestroy(b); (void)hipEventDestroy(e); b = e = NULL; return ENOMEM; }
     return 0;
 }
 
@@ -138,7 +139,8 @@ int drain_profile(rmgr_ssim_hip_Context* c)
         HIP_TRY(hipEventElapsedTime(&ms, c->pending[i].first, c->pending[i].second));
         c->prof_ms += ms;
         c->prof_launches += 1;
-        c->free_events.push_back(c->pending[i]);
+        try { c->free_events.push_back(c->pending[i]); }
+        catch (...) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     }
     c->pending.clear();
     return 0;
@@ -204,7 +206,8 @@ rmgr_ssim_hip_Context* default_context(int* err)
         if (const char* s = getenv("RMGR_SSIM_HIP_DEVICE")) dev = atoi(s);
         g_default_err = rmgr_ssim_hip_create(&g_default, dev, NULL);
         if (g_default && g_default_err == 0) {
-            if (const char* m = getenv("RMGR_SSIM_HIP_MODE")) g_default->mode = atoi(m);
+            const char* m = getenv("RMGR_SSIM_HIP_MODE");
+            if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_UNFUSED) g_default->mode = atoi(m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
             else g_default->mode = RMGR_SSIM_HIP_MODE_DOUBLE;
 #endif
@@ -344,15 +347,16 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t
     HIP_TRY(hipSetDevice(c->device));
     // One launch covers up to 65535 pairs (grid.z); larger batches go out in consecutive launches.
     const uint32_t kMaxPerLaunch = 65535;
-    std::vector<PairDesc> descs;
-    for (uint32_t first = 0; first < count; first += kMaxPerLaunch) {
+    PairDesc* descs = new (std::nothrow) PairDesc[std::min(kMaxPerLaunch, count)];
+    if (!descs) return ENOMEM;
+    int rc = 0;
+    for (uint32_t first = 0; first < count && rc == 0; first += kMaxPerLaunch) {
         const uint32_t n = std::min(kMaxPerLaunch, count - first);
-        descs.resize(n);
         for (uint32_t i = 0; i < n; ++i) descs[i] = make_desc(params[first + i]);
-        const int rc = enqueue(c, params[0].width, params[0].height, n, descs.data(), any_map, sumsDevice + first);
-        if (rc) return rc;
+        rc = enqueue(c, params[0].width, params[0].height, n, descs, any_map, sumsDevice + first);
     }
-    return 0;
+    delete[] descs;
+    return rc;
 }
 
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT
@@ -550,7 +554,13 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_C
     if (ssimMap && mapFloats && (rc = grow_device(c->stage_map, c->stage_map_cap, mapFloats))) return rc;
     if ((rc = grow_device(c->sums, c->sums_cap, channels))) return rc;
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, channels))) return rc;
-    std::vector<PairDesc> descs(channels);
+    struct Descs {               // no exceptions in here: a failed allocation is ENOMEM, like everywhere else
+        PairDesc* p;
+        explicit Descs(size_t n) : p(new (std::nothrow) PairDesc[n]) {}
+        ~Descs() { delete[] p; }
+    } descs_owner(channels);
+    PairDesc* const descs = descs_owner.p;
+    if (!descs) return ENOMEM;
     for (uint32_t ch = 0; ch < channels; ++ch) {
         PairDesc& d = descs[ch];
         // the staged copies hold the rows in the order they were copied (row 0 of a bottom-up image last)
@@ -560,7 +570,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_C
         d.map_step = d.map ? channels : 0;
         d.map_stride = d.map ? (int64_t)width * channels : 0;
     }
-    if ((rc = enqueue(c, width, height, channels, descs.data(), ssimMap != NULL && mapFloats, c->sums))) return rc;
+    if ((rc = enqueue(c, width, height, channels, descs, ssimMap != NULL && mapFloats, c->sums))) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * channels, hipMemcpyDeviceToHost, c->stream));
     if (ssimMap && mapFloats)
         HIP_TRY(hipMemcpyAsync(ssimMap, c->stage_map, sizeof(float) * mapFloats, hipMemcpyDeviceToHost, c->stream));
