@@ -175,7 +175,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     }
     hipEvent_t eb, ee;
     if ((rc = record_begin(c, eb, ee))) return rc;
-    HIP_TRY(ssim_hip::launch(geo, c->mode, variant, descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
+    HIP_TRY(ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
     return 0;
 }
 

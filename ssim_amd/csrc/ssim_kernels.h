@@ -38,6 +38,25 @@ inline bool fits_strip2(const PairDesc& d, uint32_t width, uint32_t height)
            (d.map == 0 || (d.map_step > -lim && d.map_step < lim));
 }
 
+// 2..4 when the batch is made of runs of that many descriptors whose images are the byte-interleaved channels
+// of one pair (same steps/strides, base pointers one byte apart, as rmgr_ssim_init_interleaved produces for
+// channelNum 0,1,2..); 1 otherwise.
+inline int interleaved_group(const PairDesc* d, uint32_t count)
+{
+    for (int g = 4; g >= 2; --g) {
+        if (count < (uint32_t)g || count % (uint32_t)g != 0) continue;
+        bool ok = true;
+        for (uint32_t i = 0; i < count && ok; ++i) {
+            const PairDesc& h = d[i - i % g];
+            const int64_t m = i % g;
+            ok = d[i].a == h.a + m && d[i].b == h.b + m && d[i].a_step == h.a_step && d[i].b_step == h.b_step &&
+                 d[i].a_stride == h.a_stride && d[i].b_stride == h.b_stride && h.a_step >= g && h.b_step >= g;
+        }
+        if (ok) return g;
+    }
+    return 1;
+}
+
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
 Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count);
 
@@ -45,8 +64,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
 //   descs_dev   count descriptors in device memory, or NULL when count == 1 and `single` is used
 //   partials    device scratch, >= count * geo.partials_per_image() doubles
 //   sums        device, count doubles: per-image fp64 sum of the SSIM values
+//   group       > 1 when every run of `group` consecutive descriptors addresses the interleaved channels of one
+//               image pair (interleaved_group()): scheduling hint only, results do not depend on it
 // ev_begin/ev_end (optional) are recorded around the main kernel only.
-hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* descs_dev, const PairDesc& single,
+hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end);
 
 // BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.

@@ -260,6 +260,7 @@ struct KArgs {
     const PairDesc* descs;
     uint32_t        width, height, strip_rows, strips_x, strips_y;
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
+    uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][strip_y][strip_x]
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
@@ -291,8 +292,11 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     // columns and hence cache lines -- on different L2s (measured: 3.07x the algorithmic HBM reads).  Renumber
     // so that each XCD walks one contiguous eighth of the batch's strip list (image-major, then strip row, then
     // strip column): 1.07x.  A bijection for any strip count; speed only, correctness does not depend on it.
+    // args.group > 1: the batch consists of runs of `group` sibling images that live in the same bytes (the
+    // channels of an interleaved pixel format); their strips at one position then run back to back on one XCD
+    // and share its L2 lines (position-major, sibling-minor walk) instead of each channel re-fetching them.
     const uint32_t per_img = args.strips_x * args.strips_y;
-    if ((per_img & 7u) == 0) {
+    if ((per_img & 7u) == 0 && args.group <= 1) {
         // the common case needs no division by per_img: every image's strip list splits into eighths
         const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
         const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
@@ -304,8 +308,16 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
         const uint32_t g = (blockIdx.z * args.strips_y + blockIdx.y) * args.strips_x + blockIdx.x;
         const uint32_t xcd = g & 7u, slot = g >> 3, q = total >> 3, rem = total & 7u;
         const uint32_t id = xcd * q + (xcd < rem ? xcd : rem) + slot;  // XCD k owns q (+1 for the first `rem`) strips
-        st.img = id / per_img;
-        const uint32_t lin = id - st.img * per_img;
+        uint32_t lin;
+        if (args.group > 1) {
+            const uint32_t span = per_img * args.group;
+            const uint32_t run = id / span, within = id - run * span;
+            lin = within / args.group;
+            st.img = run * args.group + (within - lin * args.group);
+        } else {
+            st.img = id / per_img;
+            lin = id - st.img * per_img;
+        }
         st.sy = lin / args.strips_x;
         st.sx = lin - st.sy * args.strips_x;
     }
@@ -917,7 +929,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     return g;
 }
 
-hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* descs_dev, const PairDesc& single,
+hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (geo.count == 0) return hipSuccess;
@@ -927,6 +939,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, const PairDesc* de
     ka.width = geo.width; ka.height = geo.height;
     ka.strip_rows = geo.strip_rows; ka.strips_x = geo.strips_x; ka.strips_y = geo.strips_y;
     ka.count = geo.count;
+    ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;
     // c1, c2: products in double, then cast (src/ssim.cpp:956-960)
     ka.c1d = (0.01 * 255.0) * (0.01 * 255.0);

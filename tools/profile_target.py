@@ -2,7 +2,8 @@
 """Minimal torch-free workload for rocprofv3 counter passes: the bench.py batch (N distinct 4096^2
 pairs resident in HBM, global SSIM only, or with the map) enqueued K times through the C ABI.
 
-usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width]
+usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width] [rgb=0]
+rgb=1: every pair is an interleaved RGB image pair (step 3) and all three channels go into the launch (3 x pairs results)
 """
 import os
 import sys
@@ -19,15 +20,27 @@ def main():
     arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
     pairs, steps, mode, want_map, w = arg(1, 8), arg(2, 5), arg(3, 0), arg(4, 0), arg(5, 4096)
     h = arg(6, w)
+    rgb = arg(7, 0)
     ctx = ssim_amd.Context(0, mode=mode)
-    params = (ssim_amd.Params * pairs)()
+    n = pairs * (3 if rgb else 1)
+    params = (ssim_amd.Params * n)()
     keep = []
     for i in range(pairs):
+        if rgb:
+            planes = [synth.pair_numpy(w, h, synth.BASE_SEED + 3 * i + c) for c in range(3)]
+            a = np.ascontiguousarray(np.stack([p[0] for p in planes], axis=-1))
+            b = np.ascontiguousarray(np.stack([p[1] for p in planes], axis=-1))
+            da, db = ctx.upload(a), ctx.upload(b)
+            keep += [da, db]
+            for c in range(3):
+                params[3 * i + c] = ssim_amd.make_params(w, h, da.ptr + c, 3, 3 * w, db.ptr + c, 3, 3 * w)
+            continue
         a, b = synth.pair_numpy(w, h, synth.BASE_SEED + i)
         da, db = ctx.upload(a), ctx.upload(b)
         dm = ctx.alloc(4 * w * h) if want_map else None
         keep += [da, db, dm]
         params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr if dm else None, 1, w)
+    pairs = n
     sums = ctx.alloc(8 * pairs)
     for _ in range(steps):
         ctx.enqueue_batch(params, pairs, sums.ptr)
