@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <strings.h>
 #include <vector>
@@ -30,6 +31,15 @@ struct Image {
     Bytes px;   // interleaved, top-down
     Image() : width(0), height(0), channels(0) {}
 };
+
+// Decoders refuse absurd headers before allocating for them (stb_image, which the reference uses, caps
+// dimensions at 2^24 as well).
+const size_t kMaxDimension = size_t(1) << 24;
+const size_t kMaxImageBytes = size_t(1) << 32;
+bool sane_size(size_t w, size_t h, size_t channels)
+{
+    return w > 0 && h > 0 && channels > 0 && w <= kMaxDimension && h <= kMaxDimension && w * h <= kMaxImageBytes / channels;
+}
 
 bool read_file(const char* path, Bytes& out)
 {
@@ -85,7 +95,7 @@ int decode_symbol(BitReader& br, const Huffman& h)
     return -1;
 }
 
-bool inflate_codes(BitReader& br, Bytes& out, const Huffman& lit, const Huffman& dist)
+bool inflate_codes(BitReader& br, Bytes& out, const Huffman& lit, const Huffman& dist, size_t limit)
 {
     static const short lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     static const short lext[29]  = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
@@ -94,6 +104,7 @@ bool inflate_codes(BitReader& br, Bytes& out, const Huffman& lit, const Huffman&
     for (;;) {
         int sym = decode_symbol(br, lit);
         if (sym < 0) return false;
+        if (out.size() > limit) return false;                 // more data than the image can hold: corrupt or hostile
         if (sym < 256) { out.push_back((unsigned char)sym); continue; }
         if (sym == 256) return true;
         sym -= 257;
@@ -107,7 +118,7 @@ bool inflate_codes(BitReader& br, Bytes& out, const Huffman& lit, const Huffman&
     }
 }
 
-bool inflate(const unsigned char* data, size_t n, Bytes& out)
+bool inflate(const unsigned char* data, size_t n, Bytes& out, size_t limit)
 {
     BitReader br(data, n);
     int last;
@@ -120,7 +131,7 @@ bool inflate(const unsigned char* data, size_t n, Bytes& out)
             if (br.pos + 4 > n) return false;
             const unsigned len = data[br.pos] | (data[br.pos + 1] << 8);
             br.pos += 4;
-            if (br.pos + len > n) return false;
+            if (br.pos + len > n || out.size() + len > limit + 65536) return false;
             out.insert(out.end(), data + br.pos, data + br.pos + len);
             br.pos += len;
         } else if (type == 1 || type == 2) {
@@ -159,7 +170,7 @@ bool inflate(const unsigned char* data, size_t n, Bytes& out)
                 build_huffman(lit, lengths, nlen);
                 build_huffman(dist, lengths + nlen, ndist);
             }
-            if (!inflate_codes(br, out, lit, dist)) return false;
+            if (!inflate_codes(br, out, lit, dist, limit)) return false;
         } else return false;
     } while (!last);
     return true;
@@ -179,7 +190,10 @@ bool decode_png(const Bytes& f, Image& img, std::string& err)
         const char* tag = reinterpret_cast<const char*>(&f[pos + 4]);
         if (pos + 12 + len > f.size()) { err = "truncated PNG chunk"; return false; }
         const unsigned char* d = &f[pos + 8];
-        if (!memcmp(tag, "IHDR", 4)) { w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12]; }
+        if (!memcmp(tag, "IHDR", 4)) {
+            if (len < 13) { err = "corrupt PNG header"; return false; }
+            w = be32(d); h = be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+        }
         else if (!memcmp(tag, "PLTE", 4)) plte.assign(d, d + len);
         else if (!memcmp(tag, "IDAT", 4)) idat.insert(idat.end(), d, d + len);
         else if (!memcmp(tag, "IEND", 4)) break;
@@ -188,11 +202,11 @@ bool decode_png(const Bytes& f, Image& img, std::string& err)
     if (interlace) { err = "interlaced PNG is not supported"; return false; }
     if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) { err = "unsupported PNG bit depth"; return false; }
     const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!samples || w == 0 || h == 0 || idat.size() < 6) { err = "unsupported or corrupt PNG"; return false; }
-    Bytes raw;
-    raw.reserve(size_t(h) * (size_t(w) * samples * depth / 8 + 2));
-    if (!inflate(&idat[2], idat.size() - 2, raw)) { err = "corrupt PNG data stream"; return false; }
+    if (!samples || !sane_size(w, h, size_t(samples) * 2) || idat.size() < 6) { err = "unsupported or corrupt PNG"; return false; }
     const size_t bpp = std::max<size_t>(1, size_t(samples) * depth / 8), rowBytes = (size_t(w) * samples * depth + 7) / 8;
+    Bytes raw;
+    raw.reserve(std::min((rowBytes + 1) * size_t(h), idat.size() * 1032 + 64));   // deflate cannot expand more than ~1032x
+    if (!inflate(&idat[2], idat.size() - 2, raw, (rowBytes + 1) * size_t(h))) { err = "corrupt PNG data stream"; return false; }
     if (raw.size() < (rowBytes + 1) * h) { err = "short PNG data stream"; return false; }
     Bytes prev(rowBytes, 0), cur(rowBytes);
     img.width = int(w); img.height = int(h); img.channels = (ctype == 3) ? 3 : samples;
@@ -236,7 +250,10 @@ bool pnm_token(const Bytes& f, size_t& pos, int& v)
     }
     if (pos >= f.size() || !isdigit(f[pos])) return false;
     v = 0;
-    while (pos < f.size() && isdigit(f[pos])) v = v * 10 + (f[pos++] - '0');
+    while (pos < f.size() && isdigit(f[pos])) {
+        if (v > 100000000) return false;
+        v = v * 10 + (f[pos++] - '0');
+    }
     return true;
 }
 
@@ -248,6 +265,7 @@ bool decode_pnm(const Bytes& f, Image& img, std::string& err)
     int w, h, maxv;
     if (!pnm_token(f, pos, w) || !pnm_token(f, pos, h) || !pnm_token(f, pos, maxv) || maxv <= 0 || maxv > 255) { err = "bad PNM header (only maxval <= 255)"; return false; }
     img.width = w; img.height = h; img.channels = (kind == 3 || kind == 6) ? 3 : 1;
+    if (!sane_size(size_t(w), size_t(h), size_t(img.channels))) { err = "bad PNM dimensions"; return false; }
     const size_t n = size_t(w) * h * img.channels;
     img.px.resize(n);
     if (kind >= 5) {
@@ -271,9 +289,10 @@ bool decode_bmp(const Bytes& f, Image& img, std::string& err)
     const int w = int(le32(&f[18])), hs = int(le32(&f[22])), bpp = int(le16(&f[28]));
     const unsigned comp = le32(&f[30]);
     if ((comp != 0 && !(comp == 3 && bpp == 32)) || !(bpp == 8 || bpp == 24 || bpp == 32) || w <= 0 || hs == 0) { err = "unsupported BMP (need uncompressed 8/24/32 bpp)"; return false; }
+    if (hs == int(0x80000000u) || !sane_size(size_t(w), size_t(hs < 0 ? -hs : hs), 4)) { err = "bad BMP dimensions"; return false; }
     const int h = hs < 0 ? -hs : hs;
     const size_t stride = ((size_t(w) * bpp + 31) / 32) * 4;
-    if (off + stride * h > f.size()) { err = "truncated BMP"; return false; }
+    if (off + stride * h > f.size() || (bpp == 8 && size_t(14) + hdr + 1024 > f.size())) { err = "truncated BMP"; return false; }
     const unsigned char* pal = &f[14 + hdr];
     img.width = w; img.height = h; img.channels = bpp == 32 ? 4 : 3;
     img.px.resize(size_t(w) * h * img.channels);
@@ -475,7 +494,7 @@ int compute_ssims(const Image& a, const Image& b, int onlyChannel, bool luminanc
 
 } // namespace
 
-int main(int argc, char* argv[])
+static int run(int argc, char* argv[])
 {
     if (argc == 2 && (!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help"))) { print_help(stdout); return EXIT_SUCCESS; }
     if (argc == 4 && !strcmp(argv[1], "--decode")) {
@@ -563,4 +582,12 @@ int main(int argc, char* argv[])
         }
     }
     return retval;
+}
+
+int main(int argc, char* argv[])
+{
+    try { return run(argc, argv); }
+    catch (const std::exception& e) { fprintf(stderr, "rmgr-ssim: %s\n", e.what()); }   // bad_alloc / length_error on hostile headers
+    catch (...) { fprintf(stderr, "rmgr-ssim: unexpected failure\n"); }
+    return EXIT_FAILURE;
 }
