@@ -16,7 +16,13 @@ HIPFLAGS := $(if $(DOUBLE),-DRMGR_SSIM_USE_DOUBLE=1) --offload-arch=$(ARCH) -O3 
 
 all: lib oracle
 
-lib: $(OUT)/librmgr-ssim-hip.so $(BIN)/rmgr-ssim
+lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim.a $(BIN)/rmgr-ssim
+
+# Static flavour under the reference's archive name (CMakeLists.txt:205): the same three objects.  A program
+# that links it also needs the HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
+$(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
+	@mkdir -p $(OUT)
+	rm -f $@ && ar rcs $@ $^
 
 $(OBJ)/ssim_kernels.o: $(SRC)/ssim_kernels.hip $(SRC)/ssim_kernels.h
 	@mkdir -p $(OBJ)
@@ -50,6 +56,7 @@ install: lib
 	install -d $(DESTDIR)$(PREFIX)/include/rmgr $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/bin $(DESTDIR)$(PREFIX)/lib/pkgconfig
 	install -m 644 include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-version.h include/rmgr/ssim-hip.h $(DESTDIR)$(PREFIX)/include/rmgr/
 	install -m 755 $(OUT)/librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/
+	install -m 644 $(OUT)/librmgr-ssim.a $(DESTDIR)$(PREFIX)/lib/
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim.so
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim-openmp.so
 	install -m 755 $(BIN)/rmgr-ssim $(DESTDIR)$(PREFIX)/bin/

@@ -149,12 +149,13 @@ def test_no_device_fails_loudly_never_computes():
     assert ei.value.errno == errno.ENODEV
 
 
-def build_dropin_client(tmp_path):
-    exe = tmp_path / "dropin_client"
+def build_dropin_client(tmp_path, static=False):
+    exe = tmp_path / ("dropin_client_static" if static else "dropin_client")
     libdir = os.path.dirname(ssim_amd.LIB_PATH)
+    link = ([os.path.join(libdir, "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"] if static
+            else ["-L", libdir, "-lrmgr-ssim-hip", "-Wl,-rpath," + libdir])
     subprocess.run(["g++", "-std=c++98", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE,
-                    os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe),
-                    "-L", libdir, "-lrmgr-ssim-hip", "-Wl,-rpath," + libdir], check=True)
+                    os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe)] + link, check=True)
     return str(exe)
 
 
@@ -182,6 +183,11 @@ def test_install_layout_and_reference_link_line(tmp_path):
                     "-L", str(prefix / "lib"), "-lrmgr-ssim-openmp", "-lrmgr-ssim", "-Wl,-rpath," + str(prefix / "lib")], check=True)
     r = subprocess.run([str(prefix / "bin" / "rmgr-ssim"), "-h"], capture_output=True, text=True)
     assert r.returncode == 0 and "Usage: rmgr-ssim" in r.stdout
+    # the static archive under the reference's name links too (plus the HIP runtime it depends on)
+    assert (prefix / "lib" / "librmgr-ssim.a").exists()
+    exe_static = tmp_path / "client_static"
+    subprocess.run(["g++", "-std=c++98", "-I", str(prefix / "include"), os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe_static),
+                    str(prefix / "lib" / "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")

@@ -276,9 +276,11 @@ def test_dropin_host_entry_points(gpu_ctx, manifest, lib):
     assert np.isnan(out.value)
 
 
-def test_reference_style_cxx98_client_on_gpu(tmp_path, manifest):
+@pytest.mark.parametrize("static", [False, True])
+def test_reference_style_cxx98_client_on_gpu(tmp_path, manifest, static):
+    """A program written against the reference's API, linked against the shared library or the static archive."""
     from test_abi_cpu import build_dropin_client
-    exe = build_dropin_client(tmp_path)
+    exe = build_dropin_client(tmp_path, static)
     il = manifest["_interleaved"]
     out = subprocess.run([exe, os.path.join(GOLDEN, il["a"]), os.path.join(GOLDEN, il["b"]), str(il["width"]), str(il["height"]), "3"],
                          check=True, capture_output=True, text=True).stdout.splitlines()
