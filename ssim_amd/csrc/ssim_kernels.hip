@@ -908,17 +908,27 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     if (strip_rows <= 0) {
-        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per
-        // SIMD on every CU: aim for >= 8 strips per CU over the whole batch (512-row strips only when
-        // that still leaves >= 32 per CU: measured +1.5 % on 32 x 4096^2, a loss with fewer).  Then even
-        // the strips out (1080 rows -> 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
-        const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256);
+        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per SIMD on
+        // every CU.  512-row strips when that leaves >= 32 strips per CU (measured +1.5 % on 32 x 4096^2 over 256,
+        // a loss with fewer); otherwise the candidate with the lowest cost under a small model fitted to
+        // measurements (u = rows + 10 halo rows is a strip's length, S = the number of SIMDs):
+        //   up to one strip per SIMD     1.37 u     (a wave that has its SIMD to itself runs ~1.46x faster than a sharing one)
+        //   up to two strips per SIMD    2 u        (the SIMDs holding two waves finish last)
+        //   more                         n u / S + 0.3 u   (throughput-bound, plus a tail)
+        // taller winning ties.  A launch that cannot fill the GPU is thereby cut into short strips: 256^2 runs as
+        // 64 strips of 8 rows in half the time of 16 strips of 32.  Strips are then evened out (1080 rows ->
+        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
+        const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
         auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count; };
+        auto evened = [&](uint32_t rows) { const uint32_t ny = height ? (height + rows - 1) / rows : 1; return height ? (height + ny - 1) / ny : rows; };
         uint32_t rows = 512;
         if (strips(rows) < cus * 32) {
-            rows = 256;
-            while (rows > 32 && strips(rows) < cus * 8)
-                rows >>= 1;
+            uint64_t best = ~(uint64_t)0;
+            for (uint32_t cand = 256; cand >= 8; cand >>= 1) {
+                const uint64_t n = strips(cand), u = evened(cand) + 10;
+                const uint64_t cost = n <= simds ? 137 * u : n <= 2 * simds ? 200 * u : 100 * n * u / simds + 30 * u;
+                if (cost < best) { best = cost; rows = cand; }
+            }
         }
         const uint32_t ny = height ? (height + rows - 1) / rows : 1;
         strip_rows = (int)(height ? (height + ny - 1) / ny : rows);
