@@ -7,8 +7,8 @@
 //   -y luminance  -> rmgr_ssim_hip_compute_ssim_luminance_host  (BT.601 conversion on the GPU)
 //   -0..-3        -> rmgr_ssim_compute_ssim                      (the plain drop-in call)
 // The reference decodes images with stb_image, which it downloads at configure time and which is not
-// available here; this tool carries its own small codecs instead: PNG (8/16-bit, non-interlaced),
-// binary/ASCII PNM, uncompressed BMP and TGA for input; PNG, PNM, BMP, TGA and PFM for the map.
+// available here; this tool carries its own small codecs instead: PNG (8/16-bit, non-interlaced), JPEG
+// (baseline and progressive Huffman), binary/ASCII PNM, uncompressed BMP and TGA for input; PNG, PNM, BMP, TGA and PFM for the map.
 #include <rmgr/ssim.h>
 #include <rmgr/ssim-hip.h>
 
@@ -329,17 +329,486 @@ bool decode_tga(const Bytes& f, Image& img, std::string& err)
     return true;
 }
 
+// ------------------------------------------------------------------------------ JPEG (baseline + progressive)
+// ITU T.81 Huffman-coded 8-bit JPEG: sequential (SOF0/SOF1) and progressive (SOF2) scans, restart intervals,
+// 1 or 3 components, sampling factors 1 or 2.  Reconstruction follows the IJG conventions every mainstream
+// decoder shares -- the 13-bit fixed-point "slow integer" inverse DCT, triangle-filter ("fancy") chroma
+// upsampling for 2:1 factors, 16-bit fixed-point YCbCr -> RGB -- so that decoded pixels agree with libjpeg
+// (checked against PIL in tests/test_cli.py).  Arithmetic coding, 12-bit, lossless and CMYK files are refused.
+const unsigned char kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21,
+                                   28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct JpegHuff {
+    bool defined;
+    int maxcode[18], valptr[17], mincode[17];
+    unsigned char vals[256];
+    JpegHuff() : defined(false) {}
+    bool build(const unsigned char* bits /* [1..16] */, const unsigned char* v, int n)
+    {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valptr[l] = k; mincode[l] = code;
+            code += bits[l]; k += bits[l];
+            if (code > (1 << l)) return false;                 // over-subscribed
+            maxcode[l] = bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7FFFFFFF;
+        if (k != n || n > 256) return false;
+        memcpy(vals, v, size_t(n));
+        defined = true;
+        return true;
+    }
+};
+
+struct JpegBits {
+    const unsigned char* p; size_t n, pos; unsigned acc; int cnt; bool hit_marker;
+    JpegBits(const unsigned char* d, size_t len, size_t start) : p(d), n(len), pos(start), acc(0), cnt(0), hit_marker(false) {}
+    void fill()
+    {
+        while (cnt <= 24) {
+            unsigned b = 0;
+            if (!hit_marker && pos < n) {
+                b = p[pos];
+                if (b == 0xFF) {
+                    if (pos + 1 < n && p[pos + 1] == 0x00) pos += 2;            // stuffed zero
+                    else { hit_marker = true; b = 0; }                             // a marker: feed zeros from here on
+                } else ++pos;
+            }
+            acc |= b << (24 - cnt);
+            cnt += 8;
+        }
+    }
+    int bit() { if (cnt < 1) fill(); const int v = int(acc >> 31); acc <<= 1; --cnt; return v; }
+    int bits(int k) { if (k == 0) return 0; if (cnt < k) fill(); const int v = int(acc >> (32 - k)); acc <<= k; cnt -= k; return v; }
+    int decode(const JpegHuff& h)
+    {
+        int code = 0;
+        for (int l = 1; l <= 16; ++l) {
+            code = (code << 1) | bit();
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+        }
+        return -1;
+    }
+    void reset() { acc = 0; cnt = 0; }
+};
+
+inline int jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
+
+struct JpegComp {
+    int id, h, v, tq, td, ta;
+    int bw, bh;            // blocks per row / column of the coefficient array (padded to whole MCUs)
+    int cw, chh;           // blocks per row / column that a non-interleaved scan visits
+    int pred;
+    std::vector<short> coef;
+    Bytes plane;           // bw*8 x bh*8 samples after the inverse DCT
+};
+
+// jidctint.c-style 8x8 inverse DCT (CONST_BITS 13, PASS1_BITS 2) on dequantised coefficients.
+void jpeg_idct(const short* in, const unsigned short* q, unsigned char* out, size_t stride)
+{
+    typedef long long W;      // 64-bit intermediates: same values as the 32-bit original on real images, no overflow on corrupt ones
+    W ws[64];
+    for (int c = 0; c < 8; ++c) {
+        const W i0 = W(in[c]) * q[c], i1 = W(in[8 + c]) * q[8 + c], i2 = W(in[16 + c]) * q[16 + c], i3 = W(in[24 + c]) * q[24 + c],
+                i4 = W(in[32 + c]) * q[32 + c], i5 = W(in[40 + c]) * q[40 + c], i6 = W(in[48 + c]) * q[48 + c], i7 = W(in[56 + c]) * q[56 + c];
+        if (!(i1 | i2 | i3 | i4 | i5 | i6 | i7)) {
+            const W dc = i0 * 4;
+            for (int r = 0; r < 8; ++r) ws[r * 8 + c] = dc;
+            continue;
+        }
+        W z1 = (i2 + i6) * 4433, t2 = z1 + i6 * -15137, t3 = z1 + i2 * 6270;
+        W t0 = (i0 + i4) * 8192, t1 = (i0 - i4) * 8192;
+        const W t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+        t0 = i7; t1 = i5; t2 = i3; t3 = i1;
+        z1 = t0 + t3; W z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+        const W z5 = (z3 + z4) * 9633;
+        t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+        z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+        z3 += z5; z4 += z5;
+        t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+        const W rnd = 1 << 10;
+        ws[0 * 8 + c] = (t10 + t3 + rnd) >> 11; ws[7 * 8 + c] = (t10 - t3 + rnd) >> 11;
+        ws[1 * 8 + c] = (t11 + t2 + rnd) >> 11; ws[6 * 8 + c] = (t11 - t2 + rnd) >> 11;
+        ws[2 * 8 + c] = (t12 + t1 + rnd) >> 11; ws[5 * 8 + c] = (t12 - t1 + rnd) >> 11;
+        ws[3 * 8 + c] = (t13 + t0 + rnd) >> 11; ws[4 * 8 + c] = (t13 - t0 + rnd) >> 11;
+    }
+    for (int r = 0; r < 8; ++r) {
+        const W* w = ws + r * 8;
+        unsigned char* o = out + size_t(r) * stride;
+        W res[8];
+        if (!(w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7])) {
+            const W dc = (w[0] + 16) >> 5;
+            for (int c = 0; c < 8; ++c) res[c] = dc;
+        } else {
+            W z1 = (w[2] + w[6]) * 4433, t2 = z1 + w[6] * -15137, t3 = z1 + w[2] * 6270;
+            W t0 = (w[0] + w[4]) * 8192, t1 = (w[0] - w[4]) * 8192;
+            const W t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+            t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
+            z1 = t0 + t3; W z2 = t1 + t2, z3 = t0 + t2, z4 = t1 + t3;
+            const W z5 = (z3 + z4) * 9633;
+            t0 *= 2446; t1 *= 16819; t2 *= 25172; t3 *= 12299;
+            z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+            z3 += z5; z4 += z5;
+            t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+            const W rnd = 1 << 17;
+            res[0] = (t10 + t3 + rnd) >> 18; res[7] = (t10 - t3 + rnd) >> 18;
+            res[1] = (t11 + t2 + rnd) >> 18; res[6] = (t11 - t2 + rnd) >> 18;
+            res[2] = (t12 + t1 + rnd) >> 18; res[5] = (t12 - t1 + rnd) >> 18;
+            res[3] = (t13 + t0 + rnd) >> 18; res[4] = (t13 - t0 + rnd) >> 18;
+        }
+        for (int c = 0; c < 8; ++c) { const W v = res[c] + 128; o[c] = (unsigned char)(v < 0 ? 0 : v > 255 ? 255 : v); }
+    }
+}
+
+struct JpegDecoder {
+    const Bytes& f;
+    std::string& err;
+    int width, height, ncomp, hmax, vmax, mcux, mcuy, restart;
+    bool progressive, adobe_rgb;
+    JpegComp comp[3];
+    unsigned short qt[4][64];
+    bool qt_set[4];
+    JpegHuff dc[4], ac[4];
+    JpegDecoder(const Bytes& file, std::string& e) : f(file), err(e), width(0), height(0), ncomp(0), hmax(1), vmax(1), mcux(0), mcuy(0), restart(0), progressive(false), adobe_rgb(false)
+    { memset(qt_set, 0, sizeof(qt_set)); }
+
+    bool fail(const char* m) { err = m; return false; }
+
+    bool read_sof(const unsigned char* d, size_t len)
+    {
+        if (len < 6 || d[0] != 8) return fail("unsupported JPEG sample precision");
+        height = (d[1] << 8) | d[2]; width = (d[3] << 8) | d[4]; ncomp = d[5];
+        if ((ncomp != 1 && ncomp != 3) || len < size_t(6 + 3 * ncomp)) return fail("unsupported JPEG component count (need greyscale or YCbCr)");
+        // the coefficient store is allocated from the header alone: cap it (2^27 pixels = 16K x 8K, 0.8 GB)
+        if (!sane_size(size_t(width), size_t(height), 3) || size_t(width) * size_t(height) > (size_t(1) << 27)) return fail("bad or oversized JPEG dimensions");
+        for (int i = 0; i < ncomp; ++i) {
+            JpegComp& c = comp[i];
+            c.id = d[6 + 3 * i]; c.h = d[7 + 3 * i] >> 4; c.v = d[7 + 3 * i] & 15; c.tq = d[8 + 3 * i];
+            if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) return fail("unsupported JPEG sampling factors");
+            hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v);
+        }
+        if (ncomp == 1) { comp[0].h = comp[0].v = 1; hmax = vmax = 1; }
+        mcux = (width + 8 * hmax - 1) / (8 * hmax); mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+        for (int i = 0; i < ncomp; ++i) {
+            JpegComp& c = comp[i];
+            c.bw = mcux * c.h; c.bh = mcuy * c.v;
+            const int sw = (width * c.h + hmax - 1) / hmax, sh = (height * c.v + vmax - 1) / vmax;
+            c.cw = (sw + 7) / 8; c.chh = (sh + 7) / 8;
+            c.coef.assign(size_t(c.bw) * c.bh * 64, 0);
+        }
+        return true;
+    }
+
+    bool read_dht(const unsigned char* d, size_t len)
+    {
+        while (len >= 17) {
+            const int tc = d[0] >> 4, th = d[0] & 15;
+            unsigned char bits[17]; bits[0] = 0;
+            int n = 0;
+            for (int i = 1; i <= 16; ++i) { bits[i] = d[i]; n += d[i]; }
+            if (tc > 1 || th > 3 || n > 256 || len < size_t(17 + n)) return fail("corrupt JPEG Huffman table");
+            if (!(tc ? ac[th] : dc[th]).build(bits, d + 17, n)) return fail("corrupt JPEG Huffman table");
+            d += 17 + n; len -= size_t(17 + n);
+        }
+        return len == 0 || fail("corrupt JPEG Huffman table");
+    }
+
+    bool read_dqt(const unsigned char* d, size_t len)
+    {
+        while (len >= 1) {
+            const int pq = d[0] >> 4, tq = d[0] & 15;
+            const size_t need = pq ? 129 : 65;
+            if (pq > 1 || tq > 3 || len < need) return fail("corrupt JPEG quantisation table");
+            for (int i = 0; i < 64; ++i) qt[tq][kZigzag[i]] = pq ? (unsigned short)((d[1 + 2 * i] << 8) | d[2 + 2 * i]) : d[1 + i];
+            qt_set[tq] = true;
+            d += need; len -= need;
+        }
+        return true;
+    }
+
+    // One entropy-coded segment.  Returns the position just behind it (at the next marker).
+    bool read_scan(const unsigned char* d, size_t len, size_t data_pos, size_t& next)
+    {
+        if (len < 1) return fail("corrupt JPEG scan header");
+        const int ns = d[0];
+        if (ns < 1 || ns > ncomp || len < size_t(4 + 2 * ns)) return fail("corrupt JPEG scan header");
+        JpegComp* sc[3];
+        for (int i = 0; i < ns; ++i) {
+            sc[i] = NULL;
+            for (int k = 0; k < ncomp; ++k) if (comp[k].id == d[1 + 2 * i]) sc[i] = &comp[k];
+            if (!sc[i]) return fail("JPEG scan names an unknown component");
+            sc[i]->td = d[2 + 2 * i] >> 4; sc[i]->ta = d[2 + 2 * i] & 15;
+            if (sc[i]->td > 3 || sc[i]->ta > 3) return fail("corrupt JPEG scan header");
+        }
+        const int ss = d[1 + 2 * ns], se = d[2 + 2 * ns], ah = d[3 + 2 * ns] >> 4, al = d[3 + 2 * ns] & 15;
+        if (progressive) {
+            if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13 || ah > 13) return fail("corrupt JPEG progressive scan");
+        } else if (ss != 0 || se != 63 || ah != 0 || al != 0) return fail("corrupt JPEG scan header");
+        for (int i = 0; i < ns; ++i) {
+            if ((ss == 0 && ah == 0 && !dc[sc[i]->td].defined) || (se > 0 && !ac[sc[i]->ta].defined)) return fail("JPEG scan uses an undefined Huffman table");
+            sc[i]->pred = 0;
+        }
+
+        JpegBits br(&f[0], f.size(), data_pos);
+        const bool interleaved = ns > 1;
+        const int nx = interleaved ? mcux : sc[0]->cw, ny = interleaved ? mcuy : sc[0]->chh;
+        int eobrun = 0, todo = restart, rst = 0;
+        for (int my = 0; my < ny; ++my) {
+            for (int mx = 0; mx < nx; ++mx) {
+                if (restart && todo == 0) {
+                    // expect RSTn at the current byte position
+                    br.reset();
+                    size_t p = br.pos;
+                    while (p + 1 < f.size() && !(f[p] == 0xFF && f[p + 1] >= 0xD0 && f[p + 1] <= 0xD7)) {
+                        if (f[p] == 0xFF && f[p + 1] != 0 && f[p + 1] != 0xFF) return fail("JPEG restart marker missing");
+                        ++p;
+                    }
+                    if (p + 1 >= f.size() || f[p + 1] != 0xD0 + rst) return fail("JPEG restart marker missing");
+                    rst = (rst + 1) & 7;
+                    br.pos = p + 2; br.hit_marker = false;
+                    for (int i = 0; i < ns; ++i) sc[i]->pred = 0;
+                    eobrun = 0; todo = restart;
+                }
+                for (int i = 0; i < ns; ++i) {
+                    JpegComp& c = *sc[i];
+                    const int bxn = interleaved ? c.h : 1, byn = interleaved ? c.v : 1;
+                    for (int by = 0; by < byn; ++by) for (int bx = 0; bx < bxn; ++bx) {
+                        const int gx = interleaved ? mx * c.h + bx : mx, gy = interleaved ? my * c.v + by : my;
+                        short* blk = &c.coef[(size_t(gy) * c.bw + gx) * 64];
+                        if (!decode_block(br, c, blk, ss, se, ah, al, eobrun)) return fail("corrupt JPEG entropy-coded data");
+                    }
+                }
+                if (restart) --todo;
+            }
+        }
+        // the next marker
+        size_t p = br.pos;
+        while (p + 1 < f.size() && !(f[p] == 0xFF && f[p + 1] != 0x00 && f[p + 1] != 0xFF && !(f[p + 1] >= 0xD0 && f[p + 1] <= 0xD7))) ++p;
+        next = p;
+        return true;
+    }
+
+    bool decode_block(JpegBits& br, JpegComp& c, short* blk, int ss, int se, int ah, int al, int& eobrun)
+    {
+        if (!progressive) {
+            int t = br.decode(dc[c.td]);
+            if (t < 0 || t > 11) return false;
+            c.pred = int(short(c.pred + jpeg_extend(br.bits(t), t)));
+            blk[0] = short(c.pred);
+            for (int k = 1; k < 64; ++k) {
+                const int rs = br.decode(ac[c.ta]);
+                if (rs < 0) return false;
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0) { if (r == 15) { k += 15; continue; } break; }
+                k += r;
+                if (k > 63) return false;
+                blk[kZigzag[k]] = short(jpeg_extend(br.bits(s), s));
+            }
+            return true;
+        }
+        if (ss == 0) {
+            if (ah == 0) {
+                const int t = br.decode(dc[c.td]);
+                if (t < 0 || t > 11) return false;
+                c.pred = int(short(c.pred + jpeg_extend(br.bits(t), t)));
+                blk[0] = short(c.pred * (1 << al));
+            } else if (br.bit()) blk[0] = short(blk[0] | (1 << al));
+            return true;
+        }
+        if (ah == 0) {                                      // AC first pass
+            if (eobrun > 0) { --eobrun; return true; }
+            for (int k = ss; k <= se; ++k) {
+                const int rs = br.decode(ac[c.ta]);
+                if (rs < 0) return false;
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0) {
+                    if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += br.bits(r); break; }
+                    k += 15;
+                    continue;
+                }
+                k += r;
+                if (k > 63) return false;
+                blk[kZigzag[k]] = short(jpeg_extend(br.bits(s), s) * (1 << al));
+            }
+            return true;
+        }
+        // AC refinement pass
+        const int p1 = 1 << al, m1 = -(1 << al);
+        int k = ss;
+        if (eobrun == 0) {
+            for (; k <= se; ++k) {
+                const int rs = br.decode(ac[c.ta]);
+                if (rs < 0) return false;
+                int r = rs >> 4, s = rs & 15;
+                if (s) { if (s != 1) return false; s = br.bit() ? p1 : m1; }
+                else if (r != 15) { eobrun = 1 << r; if (r) eobrun += br.bits(r); break; }
+                do {
+                    short& co = blk[kZigzag[k]];
+                    if (co != 0) { if (br.bit() && (co & p1) == 0) co = short(co + (co >= 0 ? p1 : m1)); }
+                    else if (--r < 0) break;
+                    ++k;
+                } while (k <= se);
+                if (s) { if (k > 63) return false; blk[kZigzag[k]] = short(s); }
+            }
+        }
+        if (eobrun > 0) {
+            for (; k <= se; ++k) {
+                short& co = blk[kZigzag[k]];
+                if (co != 0 && br.bit() && (co & p1) == 0) co = short(co + (co >= 0 ? p1 : m1));
+            }
+            --eobrun;
+        }
+        return true;
+    }
+
+    bool reconstruct(Image& img)
+    {
+        for (int i = 0; i < ncomp; ++i) {
+            JpegComp& c = comp[i];
+            if (!qt_set[c.tq]) return fail("JPEG component uses an undefined quantisation table");
+            const size_t stride = size_t(c.bw) * 8;
+            c.plane.assign(stride * c.bh * 8, 0);
+            for (int by = 0; by < c.bh; ++by) for (int bx = 0; bx < c.bw; ++bx)
+                jpeg_idct(&c.coef[(size_t(by) * c.bw + bx) * 64], qt[c.tq], &c.plane[(size_t(by) * 8) * stride + size_t(bx) * 8], stride);
+            std::vector<short>().swap(c.coef);
+        }
+        img.width = width; img.height = height; img.channels = ncomp;
+        img.px.resize(size_t(width) * height * ncomp);
+        if (ncomp == 1) {
+            for (int y = 0; y < height; ++y) memcpy(&img.px[size_t(y) * width], &comp[0].plane[size_t(y) * comp[0].bw * 8], size_t(width));
+            return true;
+        }
+        // full-resolution planes of the chroma components
+        Bytes up[3];
+        for (int i = 0; i < 3; ++i) upsample(comp[i], up[i]);
+        // YCbCr -> RGB, jdcolor.c fixed point (SCALEBITS 16)
+        for (int y = 0; y < height; ++y) {
+            const unsigned char* Y = &up[0][size_t(y) * width]; const unsigned char* Cb = &up[1][size_t(y) * width]; const unsigned char* Cr = &up[2][size_t(y) * width];
+            unsigned char* o = &img.px[size_t(y) * width * 3];
+            for (int x = 0; x < width; ++x, o += 3) {
+                if (adobe_rgb) { o[0] = Y[x]; o[1] = Cb[x]; o[2] = Cr[x]; continue; }
+                const int yy = Y[x], cb = Cb[x] - 128, cr = Cr[x] - 128;
+                const int r = yy + ((91881 * cr + 32768) >> 16);
+                const int g = yy + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+                const int b = yy + ((116130 * cb + 32768) >> 16);
+                o[0] = (unsigned char)(r < 0 ? 0 : r > 255 ? 255 : r);
+                o[1] = (unsigned char)(g < 0 ? 0 : g > 255 ? 255 : g);
+                o[2] = (unsigned char)(b < 0 ? 0 : b > 255 ? 255 : b);
+            }
+        }
+        return true;
+    }
+
+    // Component plane -> width x height samples.  2:1 factors use libjpeg's triangle filters (jdsample.c
+    // h2v1_fancy_upsample / h2v2_fancy_upsample / h1v2_fancy_upsample); rows and columns beyond the
+    // component's real extent are never read (edges replicate).
+    void upsample(const JpegComp& c, Bytes& out) const
+    {
+        const int fx = hmax / c.h, fy = vmax / c.v;
+        const int sw = (width * c.h + hmax - 1) / hmax, sh = (height * c.v + vmax - 1) / vmax;
+        const size_t stride = size_t(c.bw) * 8;
+        out.resize(size_t(width) * height);
+        if (fx == 1 && fy == 1) {
+            for (int y = 0; y < height; ++y) memcpy(&out[size_t(y) * width], &c.plane[size_t(y) * stride], size_t(width));
+            return;
+        }
+        std::vector<int> colsum(size_t(sw) + 1);
+        Bytes row(size_t(sw) * 2 + 2);
+        for (int y = 0; y < height; ++y) {
+            const int sy = fy == 2 ? y >> 1 : y;
+            const unsigned char* r0 = &c.plane[size_t(sy) * stride];
+            // vertical step: 3/4 nearer + 1/4 further source row (fy == 2), else the row itself (scaled by 4)
+            if (fy == 2) {
+                int ny = (y & 1) ? sy + 1 : sy - 1;
+                ny = ny < 0 ? 0 : (ny > sh - 1 ? sh - 1 : ny);
+                const unsigned char* r1 = &c.plane[size_t(ny) * stride];
+                for (int x = 0; x < sw; ++x) colsum[x] = 3 * r0[x] + r1[x];
+            }
+            unsigned char* o = &out[size_t(y) * width];
+            if (fx == 2 && fy == 2) {
+                // h2v2: (3*this + neighbour + 8) >> 4 and (+7), edges (4*this + 8) >> 4 and (+7)
+                for (int x = 0; x < sw; ++x) {
+                    const int t = colsum[x], l = x > 0 ? colsum[x - 1] : t, r = x < sw - 1 ? colsum[x + 1] : t;
+                    const int a = (x > 0 ? 3 * t + l + 8 : 4 * t + 8) >> 4, b = (x < sw - 1 ? 3 * t + r + 7 : 4 * t + 7) >> 4;
+                    if (2 * x < width) o[2 * x] = (unsigned char)a;
+                    if (2 * x + 1 < width) o[2 * x + 1] = (unsigned char)b;
+                }
+            } else if (fx == 2) {
+                // h2v1: (3*this + left + 1) >> 2 and (3*this + right + 2) >> 2, edges copy
+                for (int x = 0; x < sw; ++x) {
+                    const int t = r0[x];
+                    const int a = x > 0 ? (3 * t + r0[x - 1] + 1) >> 2 : t, b = x < sw - 1 ? (3 * t + r0[x + 1] + 2) >> 2 : t;
+                    if (2 * x < width) o[2 * x] = (unsigned char)a;
+                    if (2 * x + 1 < width) o[2 * x + 1] = (unsigned char)b;
+                }
+            } else {
+                // h1v2: (3*near + far + bias) >> 2 with bias 1 for the upper and 2 for the lower output row
+                const int bias = (y & 1) ? 2 : 1;
+                for (int x = 0; x < width; ++x) o[x] = (unsigned char)((colsum[x] + bias) >> 2);
+            }
+        }
+    }
+
+    bool run(Image& img)
+    {
+        if (f.size() < 4 || f[0] != 0xFF || f[1] != 0xD8) return fail("not a JPEG file");
+        size_t pos = 2;
+        bool have_sof = false, have_scan = false;
+        while (pos + 4 <= f.size()) {
+            if (f[pos] != 0xFF) { ++pos; continue; }
+            const int m = f[pos + 1];
+            if (m == 0xFF) { ++pos; continue; }
+            if (m == 0xD9) break;
+            if (m == 0x01 || (m >= 0xD0 && m <= 0xD7) || m == 0x00) { pos += 2; continue; }
+            const size_t len = (size_t(f[pos + 2]) << 8) | f[pos + 3];
+            if (len < 2 || pos + 2 + len > f.size()) return fail("truncated JPEG segment");
+            const unsigned char* d = &f[pos + 4];
+            const size_t n = len - 2;
+            if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                if (have_sof) return fail("JPEG with several frames");
+                progressive = (m == 0xC2);
+                if (!read_sof(d, n)) return false;
+                have_sof = true;
+            } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) return fail("unsupported JPEG coding process (lossless, hierarchical or arithmetic)");
+            else if (m == 0xCC) return fail("arithmetic-coded JPEG is not supported");
+            else if (m == 0xC4) { if (!read_dht(d, n)) return false; }
+            else if (m == 0xDB) { if (!read_dqt(d, n)) return false; }
+            else if (m == 0xDD) { if (n < 2) return fail("corrupt JPEG restart interval"); restart = (d[0] << 8) | d[1]; }
+            else if (m == 0xEE) { if (n >= 12 && !memcmp(d, "Adobe", 5) && d[11] == 0) adobe_rgb = true; }
+            else if (m == 0xDA) {
+                if (!have_sof) return fail("JPEG scan before frame header");
+                size_t next = 0;
+                if (!read_scan(d, n, pos + 2 + len, next)) return false;
+                have_scan = true;
+                pos = next;
+                continue;
+            }
+            pos += 2 + len;
+        }
+        if (!have_sof || !have_scan) return fail("JPEG without image data");
+        return reconstruct(img);
+    }
+};
+
+bool decode_jpeg(const Bytes& f, Image& img, std::string& err)
+{
+    JpegDecoder d(f, err);
+    return d.run(img);
+}
+
 bool load_image(const char* path, Image& img)
 {
     Bytes f;
     if (!read_file(path, f)) { fprintf(stderr, "Failed to open file \"%s\"\n", path); return false; }
-    std::string err = "unknown image format (supported: PNG, PNM, BMP, TGA)";
+    std::string err = "unknown image format (supported: PNG, JPEG, PNM, BMP, TGA)";
     bool ok = false;
     static const unsigned char pngSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     const char* ext = strrchr(path, '.');
     if (f.size() >= 8 && !memcmp(&f[0], pngSig, 8)) ok = decode_png(f, img, err);
     else if (f.size() >= 3 && f[0] == 'P' && f[1] >= '1' && f[1] <= '6') ok = decode_pnm(f, img, err);
     else if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') ok = decode_bmp(f, img, err);
+    else if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) ok = decode_jpeg(f, img, err);
     else if (ext && !strcasecmp(ext, ".tga")) ok = decode_tga(f, img, err);
     if (!ok) fprintf(stderr, "Failed to load image \"%s\":\n%s\n", path, err.c_str());
     return ok;

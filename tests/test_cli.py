@@ -129,6 +129,52 @@ def test_decodes_reference_test_pngs(tmp_path):
         assert np.array_equal(got.reshape(want.shape), want), name
 
 
+def decode_with_cli(tmp_path, path):
+    out = str(tmp_path / "jd.raw")
+    r = run("--decode", path, out)
+    assert r.returncode == 0, (path, r.stderr)
+    w, h, c = map(int, r.stdout.split())
+    return np.fromfile(out, np.uint8).reshape((h, w, c) if c > 1 else (h, w))
+
+
+def test_jpeg_decoder_matches_libjpeg(tmp_path, manifest):
+    """Baseline and progressive Huffman JPEG, 4:4:4 / 4:2:2 / 4:2:0, greyscale, odd sizes, restart intervals,
+    optimised tables, extreme qualities: every decoded sample equals libjpeg's (PIL), i.e. the slow-integer
+    IDCT, fancy upsampling and fixed-point colour conversion conventions are reproduced exactly.  The
+    reference's BBB test images are progressive 4:4:4 JPEGs (stb_image decodes them there)."""
+    Image = pytest.importorskip("PIL.Image")
+    a, _ = rgb_fixture(manifest)
+    src = Image.fromarray(a)
+    n = 0
+    for size in [a.shape[1::-1], (a.shape[1] - 3, a.shape[0] - 5), (33, 17), (8, 8), (1, 1), (17, 40)]:
+        im = src.crop((0, 0) + tuple(size))
+        for prog in (False, True):
+            for ss in (0, 1, 2):
+                for q, extra in ((30, {}), (90, {"optimize": True}), (3, {}), (100, {}), (75, {"restart_marker_blocks": 3})):
+                    p = str(tmp_path / "t.jpg")
+                    try:
+                        im.save(p, "JPEG", quality=q, progressive=prog, subsampling=ss, **extra)
+                    except (TypeError, ValueError, OSError):
+                        continue                                  # an option this PIL does not know
+                    assert np.array_equal(decode_with_cli(tmp_path, p), np.asarray(Image.open(p))), (size, prog, ss, q, extra)
+                    n += 1
+        p = str(tmp_path / "g.jpg")
+        im.convert("L").save(p, "JPEG", quality=80, progressive=True)
+        assert np.array_equal(decode_with_cli(tmp_path, p), np.asarray(Image.open(p))), size
+    assert n >= 100
+    if os.path.isdir("/root/reference/tests/images"):
+        for name in ("big_buck_bunny_360_07806_00.jpg", "big_buck_bunny_360_07806_50.jpg", "big_buck_bunny_360_07806_100.jpg"):
+            p = "/root/reference/tests/images/" + name
+            assert np.array_equal(decode_with_cli(tmp_path, p), np.asarray(Image.open(p))), name
+    # refused, not mis-decoded: arithmetic coding / 12-bit / CMYK are outside the decoder
+    bad = bytearray(open(str(tmp_path / "g.jpg"), "rb").read())
+    i = bad.index(b"\xff\xc2")
+    bad[i + 1] = 0xCA
+    open(str(tmp_path / "arith.jpg"), "wb").write(bytes(bad))
+    r = run("--decode", str(tmp_path / "arith.jpg"), str(tmp_path / "x.raw"))
+    assert r.returncode == 1 and "JPEG" in r.stderr
+
+
 def test_argument_errors(tmp_path, manifest):
     a, b = rgb_fixture(manifest)
     pa, pb, pg = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm"), str(tmp_path / "g.pgm")
@@ -166,9 +212,18 @@ def test_decoders_reject_mutated_files_without_crashing(tmp_path, manifest):
         ".bmp": b"BM" + struct.pack("<IHHI", 54 + stride * h, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, stride * h, 0, 0, 0, 0) + bytes(stride * h),
         ".tga": bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w, 0, h, 0, 24, 0]) + small.tobytes(),
     }
+    try:
+        import io
+        from PIL import Image
+        for k, (prog, ss) in enumerate(((False, 2), (True, 0), (True, 2))):
+            b = io.BytesIO()
+            Image.fromarray(small).save(b, "JPEG", quality=60, progressive=prog, subsampling=ss)
+            seeds[".%d.jpg" % k] = b.getvalue()
+    except ImportError:
+        pass
     rng = random.Random(7)
     out = str(tmp_path / "out.raw")
-    for it in range(250):
+    for it in range(400):
         ext = rng.choice(sorted(seeds))
         s = bytearray(seeds[ext])
         for _ in range(rng.randint(1, 6)):
