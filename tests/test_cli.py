@@ -318,3 +318,24 @@ def test_cli_values_and_maps_on_gpu(tmp_path, manifest, oracle):
     one = ctypes.c_float()
     rc = lib.rmgr_ssim_hip_compute_ssim_luminance_host(None, ctypes.byref(one), af.ctypes.data + (h - 1) * w * 3, -w * 3, bf.ctypes.data + (h - 1) * w * 3, -w * 3, w, h, 3, None)
     assert rc == 0 and f32_hex(one.value) == f32_hex(ov)
+
+
+@pytest.mark.gpu
+def test_cli_png_versus_jpeg_on_gpu(tmp_path, manifest, oracle):
+    """The reference tool's everyday use: an original against its JPEG-compressed copy (here: progressive 4:2:0)."""
+    Image = pytest.importorskip("PIL.Image")
+    a, _ = rgb_fixture(manifest)
+    pa, pj = str(tmp_path / "a.png"), str(tmp_path / "a_q40.jpg")
+    write_png(pa, a, 4)
+    Image.fromarray(a).save(pj, "JPEG", quality=40, progressive=True, subsampling=2)
+    j = np.asarray(Image.open(pj))
+    want = [oracle.ssim_f32(np.ascontiguousarray(a[:, :, c]), np.ascontiguousarray(j[:, :, c]))[0] for c in range(3)]
+    r = run(pa, pj)
+    assert r.returncode == 0, r.stderr
+    avg = np.float32(0)
+    for v in want:
+        avg = np.float32(avg + v)
+    assert r.stdout.splitlines() == ["Channel %u: % 7.4f" % (c, want[c]) for c in range(3)] + ["Average  : % 7.4f" % (avg / np.float32(3))]
+    ov = oracle.ssim_f32(bt601(a), bt601(j))[0]
+    r = run("-y", pa, pj)
+    assert r.returncode == 0 and r.stdout == "% 7.4f\n" % ov
