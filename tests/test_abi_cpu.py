@@ -215,3 +215,31 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert ssim_amd.get_plan(0, 0, 1).wavefronts == 0
     lib = ssim_amd.load_library()
     assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL
+
+
+def test_kernels_keep_two_waves_per_simd_and_never_spill():
+    """Build-time guard for the register cliff: the accumulator rings put every strip kernel
+    near the 256-VGPR limit of 2 waves/SIMD; one register more halves the speed (measured 122 vs 208 Gpix/s), a
+    spill is far worse.  Compile the kernels with the compiler's resource remarks and check each variant."""
+    src = os.path.join(ROOT, "ssim_amd", "csrc", "ssim_kernels.hip")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                        "-I" + INCLUDE, "-I" + os.path.dirname(src), "-c", src, "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+        for key in ("VGPRs", "ScratchSize \\[bytes/lane\\]", "Occupancy \\[waves/SIMD\\]", "LDS Size \\[bytes/block\\]"):
+            m = re.search(r"remark:\s+" + key + r": (\d+)", line)
+            if m and name:
+                kernels[name][key.split(" ")[0]] = int(m.group(1))
+    strip = {k: v for k, v in kernels.items() if "ssim_strip" in k}
+    assert len(strip) == 14, sorted(kernels)            # 3 fp32 modes x {map, no map} x 2 kernels + MODE_DOUBLE x 2
+    for k, v in strip.items():
+        assert v["ScratchSize"] == 0, (k, v)
+        assert v["VGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)
+        assert v["LDS"] <= 8192, (k, v)                 # 8 resident waves per CU must fit their slots in 64 KiB at most
