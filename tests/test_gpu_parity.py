@@ -331,6 +331,60 @@ def test_batch_equals_single_calls(gpu_ctx, oracle):
             d.free()
 
 
+def test_batches_beyond_one_launch_and_sibling_channel_order(gpu_ctx, oracle):
+    """70 000 tiny pairs: more than grid.z allows, so the ABI issues two launches (65 535 + 4 465), with strip
+    totals that are not multiples of 8 (general XCD renumbering).  Then interleaved RGB pairs whose channel
+    descriptors sit next to each other (interleaved_group(): sibling-minor strip order).  Every sum is checked."""
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    rng = np.random.default_rng(31)
+    w, h, pool, n = 13, 9, 37, 70000
+    keep = []
+    try:
+        want = []
+        bufs = []
+        for k in range(pool):
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            b = np.clip(a.astype(np.int32) + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)
+            da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+            keep += [da, db]
+            bufs.append((da.ptr, db.ptr))
+            want.append(oracle.ssim_f32(a, b)[0])
+        params = (ssim_amd.Params * n)()
+        for i in range(n):
+            pa, pb = bufs[(i * 7 + i // pool) % pool]
+            params[i] = ssim_amd.make_params(w, h, pa, 1, w, pb, 1, w)
+        sums = gpu_ctx.alloc(8 * n)
+        keep.append(sums)
+        gpu_ctx.enqueue_batch(params, n, sums.ptr)
+        gpu_ctx.synchronize()
+        got = ssim_amd.finalize(sums.download(np.float64, (n,)), w, h)
+        idx = np.array([(i * 7 + i // pool) % pool for i in range(n)])
+        exp = np.array(want, np.float32)[idx]
+        assert np.all(np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64)) <= 1)
+
+        # interleaved RGBA pairs (4 sibling channels) and RGB pairs (3), several pairs per launch
+        for ch, pairs, (hh, ww) in ((4, 3, (70, 301)), (3, 5, (33, 129)), (2, 2, (64, 256))):
+            params = (ssim_amd.Params * (ch * pairs))()
+            exp = []
+            for i in range(pairs):
+                a = rng.integers(0, 256, (hh, ww, ch), dtype=np.uint8)
+                b = np.clip(a.astype(np.int32) + rng.integers(-40, 41, a.shape), 0, 255).astype(np.uint8)
+                da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+                keep += [da, db]
+                for c in range(ch):
+                    params[ch * i + c] = ssim_amd.make_params(ww, hh, da.ptr + c, ch, ww * ch, db.ptr + c, ch, ww * ch)
+                    exp.append(oracle.ssim_f32(np.ascontiguousarray(a[:, :, c]), np.ascontiguousarray(b[:, :, c]))[0])
+            s2 = gpu_ctx.alloc(8 * ch * pairs)
+            keep.append(s2)
+            gpu_ctx.enqueue_batch(params, ch * pairs, s2.ptr)
+            gpu_ctx.synchronize()
+            got = ssim_amd.finalize(s2.download(np.float64, (ch * pairs,)), ww, hh)
+            assert all(ulp_diff(g, e) <= 1 for g, e in zip(got, exp)), (ch, pairs)
+    finally:
+        for d in keep:
+            d.free()
+
+
 def test_full_size_known_answers_and_properties(gpu_ctx, oracle, manifest):
     """BASELINE.json configs at full size: 4096^2 global (C2) and 8192^2 with map (C3), checked by
     the reference's known answers, the oracle, and size-independent properties."""
