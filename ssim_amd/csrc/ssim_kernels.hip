@@ -410,7 +410,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     // One row of pixels is in flight in registers (requested an iteration, ~1 us, before it is staged).
     // A second row in flight was measured: no gain in MODE_EXACT, -3 % in MODE_FAST (registers).
     uint8_t va[NLOAD], vb[NLOAD];
-    auto fetch = [&](int r) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
+    auto fetch_to = [&](int r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
         const int ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         const gptr_u8 ra = baseA + (int64_t)ry * pd.a_stride;
         const gptr_u8 rb = baseB + (int64_t)ry * pd.b_stride;
@@ -419,15 +419,16 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             // The empty asm keeps the zero-extension of the offset inside the loop body, where instruction
             // selection can fold it into the load (hoisted, it becomes a 64-bit VGPR pair and a 64-bit add).
             asm volatile("" : "+v"(offA[t]), "+v"(offB[t]));
-            va[t] = ra[offA[t]];
-            vb[t] = rb[offB[t]];
+            oa[t] = ra[offA[t]];
+            ob[t] = rb[offB[t]];
         }
     };
-    auto stage = [&](Slot2& s) {    // registers -> the five planes of one LDS slot
+    auto fetch = [&](int r) { fetch_to(r, va, vb); };
+    auto stage_from = [&](Slot2& s, const uint8_t (&ia)[NLOAD], const uint8_t (&ib)[NLOAD]) {    // registers -> the five planes of one LDS slot
         float* xf = reinterpret_cast<float*>(s.xx);
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            const float a = (float)va[t], b = (float)vb[t];   // retrieve_tile: uint8 -> Float
+            const float a = (float)ia[t], b = (float)ib[t];   // retrieve_tile: uint8 -> Float
             const f2 ab = {a, b};
             const float x = a * b;                            // multiply (exact for 8-bit inputs)
             const int p = sp[t];
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
         }
     };
+    auto stage = [&](Slot2& s) { stage_from(s, va, vb); };
 
     // Accumulator rings (zero == the memset of src/ssim_fma.cpp:187).
     f2 accAB[2][11], accQ[2][11], accX[11];
@@ -446,12 +448,17 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     }
     double colsum[2] = {0.0, 0.0};
 
+    // The first three rows are requested back to back (their memory latencies overlap; one strip of a small
+    // image is little more than this prologue plus 18 rows), then staged as they arrive.
     const int r_begin = y0 - 5;
-    fetch(r_begin);
-    stage(ring[0]);
-    fetch(r_begin + 1);
-    stage(ring[1]);
-    fetch(r_begin + 2);
+    {
+        uint8_t a0[NLOAD], b0[NLOAD], a1[NLOAD], b1[NLOAD];
+        fetch_to(r_begin, a0, b0);
+        fetch_to(r_begin + 1, a1, b1);
+        fetch(r_begin + 2);
+        stage_from(ring[0], a0, b0);
+        stage_from(ring[1], a1, b1);
+    }
     wave_sync();
 
     // Map addressing, like the loads: uniform row base + non-negative 32-bit byte offset per column.
@@ -665,26 +672,28 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     }
 
     uint8_t va[NLOAD], vb[NLOAD];
-    auto fetch = [&](int64_t r) {
+    auto fetch_to = [&](int64_t r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {
         const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
         const gptr_u8 ra = (gptr_u8)pd.a + ry * pd.a_stride;
         const gptr_u8 rb = (gptr_u8)pd.b + ry * pd.b_stride;
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            va[t] = ra[offA[t]];
-            vb[t] = rb[offB[t]];
+            oa[t] = ra[offA[t]];
+            ob[t] = rb[offB[t]];
         }
     };
-    auto stage = [&](Slot1& s) {
+    auto fetch = [&](int64_t r) { fetch_to(r, va, vb); };
+    auto stage_from = [&](Slot1& s, const uint8_t (&ia)[NLOAD], const uint8_t (&ib)[NLOAD]) {
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            const float a = (float)va[t], b = (float)vb[t];
+            const float a = (float)ia[t], b = (float)ib[t];
             const f2 ab = {a, b};
             s.ab[sp[t]] = ab;
             s.q[sp[t]] = ab * ab;
             s.x[sp[t]] = a * b;
         }
     };
+    auto stage = [&](Slot1& s) { stage_from(s, va, vb); };
 
     PV accAB[11], accQ[11];
     XV accX[11];
@@ -700,11 +709,14 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     const int64_t map_off = MAP ? xcol * pd.map_step : 0;
 
     const int64_t r_begin = y0 - 5;
-    fetch(r_begin);
-    stage(ring[0]);
-    fetch(r_begin + 1);
-    stage(ring[1]);
-    fetch(r_begin + 2);
+    {   // three rows requested back to back, as in the two-column kernel
+        uint8_t a0[NLOAD], b0[NLOAD], a1[NLOAD], b1[NLOAD];
+        fetch_to(r_begin, a0, b0);
+        fetch_to(r_begin + 1, a1, b1);
+        fetch(r_begin + 2);
+        stage_from(ring[0], a0, b0);
+        stage_from(ring[1], a1, b1);
+    }
     wave_sync();
 
     // Window of the lane's column: slot pixels base .. base+10 (centre base+5).
