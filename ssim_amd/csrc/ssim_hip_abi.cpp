@@ -31,13 +31,12 @@ struct rmgr_ssim_hip_Context_ {
 
     // grow-only device scratch
     double*   partials;     size_t partials_cap;   // doubles
-    double*   sums;         size_t sums_cap;       // doubles
     PairDesc* descs;        size_t descs_cap;      // entries
     uint8_t*  stage_a;      size_t stage_a_cap;    // bytes (host-pointer path)
     uint8_t*  stage_b;      size_t stage_b_cap;
     float*    stage_map;    size_t stage_map_cap;  // floats
     // pinned host scratch
-    double*   h_sums;       size_t h_sums_cap;     // doubles
+    double*   h_sums;       size_t h_sums_cap;     // doubles: per-image sums of the blocking entry points, written by the GPU
     float*    h_map[2];     size_t h_map_cap[2];   // floats: bounce buffers for the map copy-back
     hipEvent_t map_ev[2];
     PairDesc* h_descs;      size_t h_descs_cap;
@@ -250,7 +249,6 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->strip_rows = 0;
     c->variant = 0;
     c->partials = NULL; c->partials_cap = 0;
-    c->sums = NULL; c->sums_cap = 0;
     c->descs = NULL; c->descs_cap = 0;
     c->stage_a = NULL; c->stage_a_cap = 0;
     c->stage_b = NULL; c->stage_b_cap = 0;
@@ -284,7 +282,6 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
-    if (c->sums) (void)hipFree(c->sums);
     if (c->descs) (void)hipFree(c->descs);
     if (c->stage_a) (void)hipFree(c->stage_a);
     if (c->stage_b) (void)hipFree(c->stage_b);
@@ -380,17 +377,14 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* c, float* 
     int rc = validate(ssim, params, NULL);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
-    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
+    // The reduction kernel stores the sum straight into pinned host memory (mapped into the device's address
+    // space): no device-to-host copy call on the latency path, just the stream synchronisation.
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
     const PairDesc d = make_desc(*params);
-    if ((rc = enqueue(c, params->width, params->height, 1, &d, d.map != NULL, c->sums))) return rc;
-    if (ssim) {
-        HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = enqueue(c, params->width, params->height, 1, &d, d.map != NULL, c->h_sums))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ssim)
         *ssim = mean_of(c->h_sums[0], params->width, params->height);
-    } else {
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
     return 0;
 }
 
@@ -446,11 +440,9 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
         dev.ssimMap = NULL;
     }
 
-    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
     const PairDesc d = make_desc(dev);
-    if ((rc = enqueue(c, W, H, 1, &d, d.map != NULL, c->sums))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = enqueue(c, W, H, 1, &d, d.map != NULL, c->h_sums))) return rc;      // sum lands in pinned host memory
 
     if (params->ssimMap && W && H) {
         // Map back to the caller's (pageable) buffer: D2H into two pinned bounce buffers in row
@@ -552,7 +544,6 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_C
     const bool bottomA = strideA < 0, bottomB = strideB < 0;
     const size_t mapFloats = (size_t)width * height * channels;
     if (ssimMap && mapFloats && (rc = grow_device(c->stage_map, c->stage_map_cap, mapFloats))) return rc;
-    if ((rc = grow_device(c->sums, c->sums_cap, channels))) return rc;
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, channels))) return rc;
     struct Descs {               // no exceptions in here: a failed allocation is ENOMEM, like everywhere else
         PairDesc* p;
@@ -570,8 +561,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_channels_host(rmgr_ssim_hip_C
         d.map_step = d.map ? channels : 0;
         d.map_stride = d.map ? (int64_t)width * channels : 0;
     }
-    if ((rc = enqueue(c, width, height, channels, descs, ssimMap != NULL && mapFloats, c->sums))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double) * channels, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = enqueue(c, width, height, channels, descs, ssimMap != NULL && mapFloats, c->h_sums))) return rc;
     if (ssimMap && mapFloats)
         HIP_TRY(hipMemcpyAsync(ssimMap, c->stage_map, sizeof(float) * mapFloats, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -603,7 +593,6 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_
     yb += (4 - (reinterpret_cast<uintptr_t>(yb) & 3u)) & 3u;
     HIP_TRY(ssim_hip::launch_luminance(ya, (int64_t)ypitch, sp.a, channels, (int64_t)sp.pitch, width, height, c->stream));
     HIP_TRY(ssim_hip::launch_luminance(yb, (int64_t)ypitch, sp.b, channels, (int64_t)sp.pitch, width, height, c->stream));
-    if ((rc = grow_device(c->sums, c->sums_cap, 1))) return rc;
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
     PairDesc d;
     const bool bottomA = strideA < 0, bottomB = strideB < 0;
@@ -612,8 +601,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_
     d.map = (ssimMap && mapFloats) ? c->stage_map : NULL;
     d.map_step = d.map ? 1 : 0;
     d.map_stride = d.map ? width : 0;
-    if ((rc = enqueue(c, width, height, 1, &d, d.map != NULL, c->sums))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_sums, c->sums, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = enqueue(c, width, height, 1, &d, d.map != NULL, c->h_sums))) return rc;
     if (d.map)
         HIP_TRY(hipMemcpyAsync(ssimMap, c->stage_map, sizeof(float) * mapFloats, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
