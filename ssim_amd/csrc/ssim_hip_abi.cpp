@@ -37,6 +37,7 @@ struct rmgr_ssim_hip_Context_ {
     float*    stage_map;    size_t stage_map_cap;  // floats
     // pinned host scratch
     double*   h_sums;       size_t h_sums_cap;     // doubles: per-image sums of the blocking entry points, written by the GPU
+    uint8_t*  h_stage;      size_t h_stage_cap;    // bytes: small image pairs are gathered here for one DMA
     float*    h_map[2];     size_t h_map_cap[2];   // floats: bounce buffers for the map copy-back
     hipEvent_t map_ev[2];
     PairDesc* h_descs;      size_t h_descs_cap;
@@ -55,6 +56,8 @@ struct rmgr_ssim_hip_Context_ {
 };
 
 namespace {
+
+const size_t kSmallStageBytes = size_t(768) << 10;   // image pairs up to this many bytes go through one pinned gather copy
 
 int map_hip_error(hipError_t e)
 {
@@ -254,6 +257,7 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->stage_b = NULL; c->stage_b_cap = 0;
     c->stage_map = NULL; c->stage_map_cap = 0;
     c->h_sums = NULL; c->h_sums_cap = 0;
+    c->h_stage = NULL; c->h_stage_cap = 0;
     c->h_descs = NULL; c->h_descs_cap = 0;
     c->descs_live = 0;
     c->h_map[0] = c->h_map[1] = NULL; c->h_map_cap[0] = c->h_map_cap[1] = 0;
@@ -287,6 +291,7 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     if (c->stage_b) (void)hipFree(c->stage_b);
     if (c->stage_map) (void)hipFree(c->stage_map);
     if (c->h_sums) (void)hipHostFree(c->h_sums);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_descs) (void)hipHostFree(c->h_descs);
     for (int i = 0; i < 2; ++i) { if (c->h_map[i]) (void)hipHostFree(c->h_map[i]); if (c->map_ev[i]) (void)hipEventDestroy(c->map_ev[i]); }
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -424,12 +429,25 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
         extent(params->imgA, W, H, loA, hiA);
         extent(params->imgB, W, H, loB, hiB);
         const size_t nA = (size_t)(hiA - loA + 1), nB = (size_t)(hiB - loB + 1);
-        if ((rc = grow_device(c->stage_a, c->stage_a_cap, nA))) return rc;
-        if ((rc = grow_device(c->stage_b, c->stage_b_cap, nB))) return rc;
-        HIP_TRY(hipMemcpyAsync(c->stage_a, params->imgA.topLeft + loA, nA, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->stage_b, params->imgB.topLeft + loB, nB, hipMemcpyHostToDevice, c->stream));
-        dev.imgA.topLeft = c->stage_a - loA;
-        dev.imgB.topLeft = c->stage_b - loB;
+        if (nA + nB <= kSmallStageBytes) {
+            // Small images: two pageable copies cost ~12 us each in driver overhead.  Gather both byte ranges in
+            // one pinned buffer (a ~4 us memcpy at this size) and send them with a single DMA.
+            const size_t offB = (nA + 63) & ~(size_t)63;
+            if ((rc = grow_pinned(c->h_stage, c->h_stage_cap, offB + nB))) return rc;
+            if ((rc = grow_device(c->stage_a, c->stage_a_cap, offB + nB))) return rc;
+            memcpy(c->h_stage, params->imgA.topLeft + loA, nA);
+            memcpy(c->h_stage + offB, params->imgB.topLeft + loB, nB);
+            HIP_TRY(hipMemcpyAsync(c->stage_a, c->h_stage, offB + nB, hipMemcpyHostToDevice, c->stream));
+            dev.imgA.topLeft = c->stage_a - loA;
+            dev.imgB.topLeft = c->stage_a + offB - loB;
+        } else {
+            if ((rc = grow_device(c->stage_a, c->stage_a_cap, nA))) return rc;
+            if ((rc = grow_device(c->stage_b, c->stage_b_cap, nB))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->stage_a, params->imgA.topLeft + loA, nA, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->stage_b, params->imgB.topLeft + loB, nB, hipMemcpyHostToDevice, c->stream));
+            dev.imgA.topLeft = c->stage_a - loA;
+            dev.imgB.topLeft = c->stage_b - loB;
+        }
         if (params->ssimMap) {
             if ((rc = grow_device(c->stage_map, c->stage_map_cap, (size_t)W * H))) return rc;
             dev.ssimMap = c->stage_map;      // dense W x H on the device
