@@ -9,6 +9,7 @@
  *
  *   rmgr_ssim_hip_compute_ssim_host    rmgr::ssim::compute_ssim           src/ssim.cpp:933-1106
  *   rmgr_ssim_hip_compute_ssim_device  same, images/map already in HBM    src/ssim.cpp:933-1106
+ *   rmgr_ssim_hip_compute_ssim_batch_host  a caller's loop over host pairs  sample/rmgr-ssim-sample.cpp:84-95
  *   rmgr_ssim_hip_enqueue_batch        the caller-side loop over pairs    src/ssim-cli.cpp:197-210
  *                                      + per-thread fp64 partials         src/ssim.cpp:902-926
  *   rmgr_ssim_hip_finalize             the final mean                     src/ssim.cpp:1090-1103
@@ -91,6 +92,16 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* ctx, float
  */
 rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
                                          double* sumsDevice) RMGR_NOEXCEPT;
+
+/*
+ * A batch of HOST image pairs (identical width/height, global SSIM only: every ssimMap must be NULL): what a
+ * caller looping rmgr_ssim_compute_ssim() over frames does (sample/rmgr-ssim-sample.cpp:84-95, src/ssim-cli.cpp:
+ * 197-210), with the staging pipelined -- pairs are copied to the GPU in chunks on a second stream while the kernels
+ * of the previous chunk run, small pairs are gathered in pinned memory and sent with one DMA per chunk.  ssim[i]
+ * is bit-identical to the single-pair call on pair i.  ctx may be NULL (process-wide default context).  Blocking.
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
+                                                   float* ssim) RMGR_NOEXCEPT;
 
 /* ssim[i] = float(sums[i] / double(width*height)) with the reference's 32-bit product (src/ssim.cpp:1102).  Host arrays. */
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT;

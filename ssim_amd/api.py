@@ -64,7 +64,7 @@ C_SYMBOLS = [
     "rmgr_ssim_compute_ssim", "rmgr_ssim_compute_ssim_openmp",
     "rmgr_ssim_hip_get_device_count", "rmgr_ssim_hip_create", "rmgr_ssim_hip_destroy", "rmgr_ssim_hip_set_mode",
     "rmgr_ssim_hip_get_mode", "rmgr_ssim_hip_set_tuning", "rmgr_ssim_hip_get_plan", "rmgr_ssim_hip_compute_ssim_host",
-    "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
+    "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_compute_ssim_batch_host", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
@@ -109,6 +109,7 @@ def load_library(path=None):
         "rmgr_ssim_hip_compute_ssim_host": [vp, ctypes.POINTER(ctypes.c_float), PP, ctypes.POINTER(ThreadPool)],
         "rmgr_ssim_hip_compute_ssim_device": [vp, ctypes.POINTER(ctypes.c_float), PP],
         "rmgr_ssim_hip_enqueue_batch": [vp, u32, PP, vp],
+        "rmgr_ssim_hip_compute_ssim_batch_host": [vp, u32, PP, ctypes.POINTER(ctypes.c_float)],
         "rmgr_ssim_hip_finalize": [u32, ctypes.POINTER(ctypes.c_double), u32, u32, ctypes.POINTER(ctypes.c_float)],
         "rmgr_ssim_hip_synchronize": [vp],
         "rmgr_ssim_hip_malloc": [vp, ctypes.POINTER(vp), ctypes.c_size_t],
@@ -203,6 +204,20 @@ def compute_ssim(a, b, want_map=False, openmp=False, allocator=False, out_map=No
     else:
         _check("rmgr_ssim_compute_ssim", lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None))
     return np.float32(out.value), m
+
+
+def compute_ssim_batch(pairs, ctx=None):
+    """Global SSIM of many host image pairs of one size (rmgr_ssim_hip_compute_ssim_batch_host: pipelined staging).
+    pairs: sequence of (a, b) uint8 arrays, H x W (any strides numpy can express along both axes)."""
+    lib = load_library()
+    n = len(pairs)
+    params = (Params * n)()
+    for i, (a, b) in enumerate(pairs):
+        h, w = a.shape
+        params[i] = make_params(w, h, a.ctypes.data, a.strides[1], a.strides[0], b.ctypes.data, b.strides[1], b.strides[0])
+    out = (ctypes.c_float * n)()
+    _check("rmgr_ssim_hip_compute_ssim_batch_host", lib.rmgr_ssim_hip_compute_ssim_batch_host(ctx.handle if ctx is not None else None, n, params, out))
+    return np.array(out[:], np.float32)
 
 
 def compute_ssim_channels(a, b, want_map=False):

@@ -37,6 +37,12 @@ struct rmgr_ssim_hip_Context_ {
     float*    stage_map;    size_t stage_map_cap;  // floats
     // pinned host scratch
     double*   h_sums;       size_t h_sums_cap;     // doubles: per-image sums of the blocking entry points, written by the GPU
+    // pipelined host batches: two device slots, two pinned gather buffers, a copy stream and per-slot events
+    uint8_t*  slot_dev[2];  size_t slot_dev_cap[2];
+    uint8_t*  slot_pin[2];  size_t slot_pin_cap[2];
+    double*   batch_sums;   size_t batch_sums_cap;
+    hipStream_t copy_stream;
+    hipEvent_t  slot_copied[2], slot_done[2];
     uint8_t*  h_stage;      size_t h_stage_cap;    // bytes: small image pairs are gathered here for one DMA
     float*    h_map[2];     size_t h_map_cap[2];   // floats: bounce buffers for the map copy-back
     hipEvent_t map_ev[2];
@@ -258,6 +264,9 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->stage_map = NULL; c->stage_map_cap = 0;
     c->h_sums = NULL; c->h_sums_cap = 0;
     c->h_stage = NULL; c->h_stage_cap = 0;
+    for (int i = 0; i < 2; ++i) { c->slot_dev[i] = c->slot_pin[i] = NULL; c->slot_dev_cap[i] = c->slot_pin_cap[i] = 0; c->slot_copied[i] = c->slot_done[i] = NULL; }
+    c->batch_sums = NULL; c->batch_sums_cap = 0;
+    c->copy_stream = NULL;
     c->h_descs = NULL; c->h_descs_cap = 0;
     c->descs_live = 0;
     c->h_map[0] = c->h_map[1] = NULL; c->h_map_cap[0] = c->h_map_cap[1] = 0;
@@ -292,6 +301,14 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     if (c->stage_map) (void)hipFree(c->stage_map);
     if (c->h_sums) (void)hipHostFree(c->h_sums);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < 2; ++i) {
+        if (c->slot_dev[i]) (void)hipFree(c->slot_dev[i]);
+        if (c->slot_pin[i]) (void)hipHostFree(c->slot_pin[i]);
+        if (c->slot_copied[i]) (void)hipEventDestroy(c->slot_copied[i]);
+        if (c->slot_done[i]) (void)hipEventDestroy(c->slot_done[i]);
+    }
+    if (c->batch_sums) (void)hipFree(c->batch_sums);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_descs) (void)hipHostFree(c->h_descs);
     for (int i = 0; i < 2; ++i) { if (c->h_map[i]) (void)hipHostFree(c->h_map[i]); if (c->map_ev[i]) (void)hipEventDestroy(c->map_ev[i]); }
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
@@ -359,6 +376,97 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t
     }
     delete[] descs;
     return rc;
+}
+
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* c, rmgr_uint32_t count, const rmgr_ssim_Params* params, float* ssim) RMGR_NOEXCEPT
+{
+    if (count && (!params || !ssim)) return EINVAL;
+    if (count == 0) return 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (params[i].imgA.topLeft == NULL || params[i].imgB.topLeft == NULL || params[i].ssimMap != NULL) return EINVAL;
+        if (params[i].width != params[0].width || params[i].height != params[0].height) return EINVAL;
+    }
+    int rc = 0;
+    std::unique_lock<std::mutex> guard;
+    if (!c) {
+        c = default_context(&rc);
+        if (rc) return rc;
+        if (!c) return ENODEV;
+        guard = std::unique_lock<std::mutex>(c->lock);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t W = params[0].width, H = params[0].height;
+    if (W == 0 || H == 0) {                       // 0/0, like the single call
+        for (uint32_t i = 0; i < count; ++i) ssim[i] = mean_of(0.0, W, H);
+        return 0;
+    }
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!c->slot_copied[i]) HIP_TRY(hipEventCreateWithFlags(&c->slot_copied[i], hipEventDisableTiming));
+        if (!c->slot_done[i]) HIP_TRY(hipEventCreateWithFlags(&c->slot_done[i], hipEventDisableTiming));
+    }
+    if ((rc = grow_device(c->batch_sums, c->batch_sums_cap, count))) return rc;
+    if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, count))) return rc;
+
+    const size_t kChunkBytes = size_t(48) << 20, kAlign = 256;
+    const uint32_t kMaxChunkPairs = 4096;
+    PairDesc* descs = new (std::nothrow) PairDesc[std::min(count, kMaxChunkPairs)];
+    if (!descs) return ENOMEM;
+    struct Free { PairDesc* p; ~Free() { delete[] p; } } free_descs = {descs};
+    (void)free_descs;
+
+    bool slot_busy[2] = {false, false};
+    uint32_t first = 0;
+    for (int k = 0; first < count; ++k) {
+        const int slot = k & 1;
+        // this chunk: as many pairs as fit the byte budget (at least one)
+        uint32_t n = 0;
+        size_t bytes = 0;
+        bool small = true;
+        while (first + n < count && n < kMaxChunkPairs) {
+            int64_t loA, hiA, loB, hiB;
+            extent(params[first + n].imgA, W, H, loA, hiA);
+            extent(params[first + n].imgB, W, H, loB, hiB);
+            const size_t nA = (size_t)(hiA - loA + 1), nB = (size_t)(hiB - loB + 1);
+            const size_t need = ((nA + kAlign - 1) & ~(kAlign - 1)) + ((nB + kAlign - 1) & ~(kAlign - 1));
+            if (n > 0 && bytes + need > kChunkBytes) break;
+            bytes += need;
+            small = small && (nA + nB <= kSmallStageBytes);
+            ++n;
+        }
+        // the slot's previous occupant (chunk k-2) must have been consumed
+        if (slot_busy[slot]) HIP_TRY(hipEventSynchronize(c->slot_done[slot]));
+        if ((rc = grow_device(c->slot_dev[slot], c->slot_dev_cap[slot], bytes))) return rc;
+        if (small && (rc = grow_pinned(c->slot_pin[slot], c->slot_pin_cap[slot], bytes))) return rc;
+        size_t off = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const rmgr_ssim_Params& p = params[first + i];
+            rmgr_ssim_Params dev = p;
+            const rmgr_ssim_ImgParams* src[2] = {&p.imgA, &p.imgB};
+            rmgr_ssim_ImgParams* dst[2] = {&dev.imgA, &dev.imgB};
+            for (int j = 0; j < 2; ++j) {
+                int64_t lo, hi;
+                extent(*src[j], W, H, lo, hi);
+                const size_t nb = (size_t)(hi - lo + 1);
+                if (small) memcpy(c->slot_pin[slot] + off, src[j]->topLeft + lo, nb);
+                else HIP_TRY(hipMemcpyAsync(c->slot_dev[slot] + off, src[j]->topLeft + lo, nb, hipMemcpyHostToDevice, c->copy_stream));
+                dst[j]->topLeft = c->slot_dev[slot] + off - lo;
+                off += (nb + kAlign - 1) & ~(kAlign - 1);
+            }
+            descs[i] = make_desc(dev);
+        }
+        if (small) HIP_TRY(hipMemcpyAsync(c->slot_dev[slot], c->slot_pin[slot], bytes, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(hipEventRecord(c->slot_copied[slot], c->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->slot_copied[slot], 0));
+        if ((rc = enqueue(c, W, H, n, descs, false, c->batch_sums + first))) return rc;
+        HIP_TRY(hipEventRecord(c->slot_done[slot], c->stream));
+        slot_busy[slot] = true;
+        first += n;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_sums, c->batch_sums, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (uint32_t i = 0; i < count; ++i) ssim[i] = mean_of(c->h_sums[i], W, H);
+    return 0;
 }
 
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT

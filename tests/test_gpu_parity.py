@@ -524,3 +524,41 @@ def test_two_contexts_and_mode_switching(gpu_ctx, manifest):
         assert f32_hex(other.ssim_planes(a, b)[0]) == ent["fma"]["ssim_hex"]
     finally:
         other.close()
+
+
+def test_pipelined_host_batch_equals_single_host_calls(oracle):
+    """rmgr_ssim_hip_compute_ssim_batch_host: chunked, double-buffered staging on a second stream.  Results must be
+    the single-pair host call's, bit for bit, for small pairs (pinned gather path), large pairs (direct copies,
+    several chunks), odd layouts, and a batch that spans many chunks."""
+    rng = np.random.default_rng(77)
+
+    def pairs_of(h, w, n, flip=False):
+        out = []
+        for i in range(n):
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            b = np.clip(a.astype(np.int32) + rng.integers(-35, 36, (h, w)), 0, 255).astype(np.uint8)
+            if flip and i % 2:
+                a, b = a[::-1, ::-1], b[:, ::-1]          # negative strides / steps as views
+            out.append((a, b))
+        return out
+
+    for (h, w, n, flip) in [(64, 96, 300, False), (33, 17, 50, True), (480, 640, 40, False), (1080, 1920, 30, False), (2100, 4099, 5, True)]:
+        ps = pairs_of(h, w, n, flip)
+        got = ssim_amd.compute_ssim_batch(ps)
+        for i in range(0, n, max(1, n // 7)):
+            a, b = ps[i]
+            single, _ = ssim_amd.compute_ssim(np.ascontiguousarray(a), np.ascontiguousarray(b))
+            assert f32_hex(got[i]) == f32_hex(single), (h, w, i)
+        ov = oracle.ssim_f32(np.ascontiguousarray(ps[-1][0]), np.ascontiguousarray(ps[-1][1]), threads=4)[0]
+        assert ulp_diff(got[-1], ov) <= 1
+    # argument checks: maps are not supported, sizes must agree
+    a = np.zeros((8, 8), np.uint8)
+    m = np.zeros((8, 8), np.float32)
+    lib = ssim_amd.load_library()
+    p = (ssim_amd.Params * 1)(ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8, m.ctypes.data, 1, 8))
+    out = (ctypes.c_float * 1)()
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 1, p, out) == errno.EINVAL
+    p2 = (ssim_amd.Params * 2)(ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8), ssim_amd.make_params(8, 4, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8))
+    out2 = (ctypes.c_float * 2)()
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 2, p2, out2) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 0, None, None) == 0
