@@ -121,6 +121,16 @@ def test_validation_order_matches_reference(lib):
     assert lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(good), ctypes.byref(tp)) == errno.EINVAL   # threadCount == 0
     assert lib.rmgr_ssim_hip_finalize(1, None, 8, 8, None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_enqueue_batch(None, 1, ctypes.byref(good), None) == errno.EINVAL
+    # the pipelined host batch validates before it looks for a device: NULL arrays, maps, mixed sizes
+    outs = (ctypes.c_float * 2)()
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 1, None, outs) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 1, ctypes.byref(good), None) == errno.EINVAL
+    m = np.zeros((8, 8), np.float32)
+    with_map = ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8, m.ctypes.data, 1, 8)
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 1, ctypes.byref(with_map), outs) == errno.EINVAL
+    mixed = (ssim_amd.Params * 2)(good, ssim_amd.make_params(8, 4, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8))
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 2, mixed, outs) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 0, None, None) == 0
 
 
 def test_finalize_is_the_reference_mean():
