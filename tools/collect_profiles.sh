@@ -21,7 +21,7 @@ for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920
   pmc ${tag}_fetch FETCH_SIZE "$@"
   pmc ${tag}_write WRITE_SIZE "$@"
   pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
-  pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
+  pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
 done
 # kernel-only speeds per mode (HIP events, tools/ab.py): batch of 8, single pair, with map
 {
