@@ -2,18 +2,28 @@
 """bench.py -- the reference's headline metric on MI355X: Mpix/s of compute_ssim (global SSIM,
 no map) on 4096x4096 uint8 pairs, with the achieved-vs-roofline figures and a CPU baseline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--workload ...]
 
-A "step" is one pass of the hot path over one batch: PAIRS_PER_GPU distinct synthetic 4096x4096
-pairs per GPU (BASELINE.json configs[1] image; seeds 0x5EED+i), resident in HBM,
-one batched launch through the C ABI (rmgr_ssim_hip_enqueue_batch), and -- for N > 1 -- one RCCL
-all-reduce of the per-image fp64 sums so that every rank holds every result (images are sharded
-by rank, weak scaling: per-GPU work is fixed).  Timing: barrier + synchronize on both sides of
-exactly K steps, max over ranks; value = all pixels of all ranks / that time.
+`--gpus N` with N > 1 is self-contained, like the reference's rmgr_ssim_compute_ssim_openmp builds its
+own pool (src/ssim-openmp.c:40-47): when no launcher has set WORLD_SIZE, this process -- before it
+imports torch or touches HIP -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ... bench.py <same flags>` as a CHILD process (never exec), relays its output
+(rank 0 prints the JSON line) and exits with its code.  Launched under torch.distributed.run by someone
+else (RANK / LOCAL_RANK / WORLD_SIZE set) it is simply one of the ranks.
 
-Before any timing the results are gated on the reference's known answer for pair 0
-(FMA path: 0x3f64b7be = 0.893428683).
+A "step" is one pass of the hot path over one batch: distinct synthetic pairs (seeds 0x5EED+i,
+SURVEY.md 8(d)) resident in HBM, one batched launch per rank through the C ABI
+(rmgr_ssim_hip_enqueue_batch), and -- for N > 1 -- one RCCL all-reduce of the per-image fp64 sums so
+that every rank holds every result.  Images are sharded by rank:
+    --scaling weak   (default) every rank owns PAIRS pairs: per-GPU work is fixed;
+    --scaling strong the workload's total batch (e.g. BASELINE.json configs[3]: 1024 x 1080p) is split
+                     over the ranks with sharding.split_batch: total work is fixed.
+Timing: barrier + synchronize on both sides of exactly K steps, max over ranks; value = all pixels of
+all ranks / that time.  Before any timing the results are gated on the reference's known answers
+(FMA path float bits) -- on every rank's first pairs.
+
+After the headline the same run times the other BASELINE.json configs on rank 0 (8192^2 + map exact
+and separable, 128 x 1080p, fp64 internals 4096^2 + map), each KAT-gated, into `configs`.
 
 Only the cpu_baseline leg touches oracle/: it times the real reference kernels (oracle/_ref,
 kind "reference") or, where that prebuilt library is absent, the C restatement (kind "port").
@@ -22,71 +32,143 @@ import argparse
 import ctypes
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W = H = 4096
-PAIRS_PER_GPU = 32
-KAT_PAIR0_HEX = 0x3f64b7be            # reference FMA path on seed 0x5EED (tests/golden/manifest.json)
-BYTES_PER_PIXEL = 2                   # algorithmic HBM bytes, global-only: one uint8 from each image
 # BASELINE.json configs as selectable workloads; the default ("4k") is the one the metric is quoted on.
-#   name: (width, height, pairs per GPU, write map, KAT of pair 0 = reference FMA float bits, description)
+#   name: (width, height, pairs per GPU (weak), total pairs (strong), write map, KATs of the first pairs =
+#          reference FMA float bits for seeds 0x5EED, 0x5EEE, ..., description)
 WORKLOADS = {
-    "4k":     (4096, 4096, 32, False, 0x3f64b7be, "4096x4096 uint8 pairs (BASELINE.json configs[1] image), global SSIM only"),
-    "8k-map": (8192, 8192, 2, True, 0x3f64b5b4, "8192x8192 uint8 pairs with per-pixel SSIM map writeback (BASELINE.json configs[2])"),
-    "1080p":  (1920, 1080, 128, False, 0x3f64bb1f, "1920x1080 uint8 pairs, global SSIM only (BASELINE.json configs[3]: 1024 pairs over 8 GPUs = 128 per GPU)"),
+    "4k":     (4096, 4096, 32, 256, False, (0x3f64b7be,), "4096x4096 uint8 pairs (BASELINE.json configs[1] image), global SSIM only"),
+    "8k-map": (8192, 8192, 2, 16, True, (0x3f64b5b4,), "8192x8192 uint8 pairs with per-pixel SSIM map writeback (BASELINE.json configs[2])"),
+    "1080p":  (1920, 1080, 128, 1024, False, (0x3f64bb1f, 0x3f64bbf6, 0x3f64bb30),
+               "1920x1080 uint8 pairs, global SSIM only (BASELINE.json configs[3]: 1024 pairs over 8 GPUs = 128 per GPU)"),
 }
+NAIVE_F64_4K = 0.893428737869049      # tests/ssim_naive.h compute_ssim<double> on the 4096^2 seed-0x5EED pair
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-# fp32 VALU work of MODE_EXACT per output pixel: 5 planes x (5 fold adds + 6 mul + 30 fma
-# + 10 ring adds) + 23 for the SSIM formula/divide/fp64 accumulate = 278 lane-ops
-VALU_OPS_PER_PIXEL = 278
+# fp32 VALU work per output pixel: exact = 5 planes x (5 fold adds + 6 mul + 30 fma + 10 ring adds)
+# + 23 for the SSIM formula / divide / fp64 accumulate; separable = 5 x 22 + 23; fp64 mode = 108 fp64 ops
+VALU_OPS_PER_PIXEL = {0: 278, 1: 133, 2: 108, 3: 278}
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
+VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
 VALU_MEASURED_2WAVE_TOPS = 58.1       # the same probe at the 2 waves/SIMD the kernel's 110 accumulator VGPRs allow
+MODE_NAMES = ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double (fp64 internals)", "unfused (reference AVX order)"]
 
 
-def cpu_baseline(budget_s=12.0):
-    """Reference FMA+OpenMP path (or the port) on this box's host cores, one 4096^2 pair."""
+# ------------------------------------------------------------------------------------------------
+# self-launch (no torch, no HIP before this returns)
+# ------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_command(n, argv, port=None):
+    """The torch.distributed.run command line that starts `n` ranks of this script with `argv`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["SSIM_BENCH_CHILD"] = "1"
+    cmd = launcher_command(n, argv)
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the only user of oracle/)
+# ------------------------------------------------------------------------------------------------
+def host_cpu():
+    model, procs = "unknown", os.cpu_count()
+    try:
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("model name"):
+                    model = l.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, procs
+
+
+def cpu_baseline(budget_s=10.0):
+    """Reference FMA+OpenMP path (or the port) on this box's host cores.  Headline: one 4096^2 pair, global only,
+    all threads (the reference caps its pool at 64, src/ssim.cpp:1025), repeated for ~budget_s; plus, per BASELINE
+    config, one thread and all threads (the table the reference's own test binary prints, tests/rmgr-ssim-tests.cpp:188-222)."""
     import numpy as np
     import oracle
-    a, b = oracle.synth_pair(W, H, 0x5EED)
     if oracle.have_ref():
         kind = "reference"
-        cores = min(oracle.ref_lib().ref_max_threads(), 64)      # the reference caps its pool at 64 (src/ssim.cpp:1025)
-        fn = lambda: oracle.ref_ssim(a, b, impl=5, threads=cores)
+        cores = min(oracle.ref_lib().ref_max_threads(), 64)
+        run = lambda a, b, threads, want_map=False: oracle.ref_ssim(a, b, want_map=want_map, impl=5, threads=threads)
     else:
         kind = "port"
         cores = oracle.oracle_lib().oracle_max_threads()
-        fn = lambda: oracle.ssim_f32(a, b, fused=True, threads=cores)
-    v = fn()[0]
-    assert int(np.float32(v).view(np.uint32)) == KAT_PAIR0_HEX, "CPU baseline disagrees with the known answer"
-    times = []
-    t_stop = time.perf_counter() + budget_s          # a bounded sample: ~12 s of all-core work
-    while time.perf_counter() < t_stop:
-        t0 = time.perf_counter()
-        fn()
-        times.append(time.perf_counter() - t0)
-    t1 = time.perf_counter()
-    oracle_1t = oracle.ref_ssim(a, b, impl=5, threads=1) if kind == "reference" else oracle.ssim_f32(a, b, threads=1)
-    t_single = time.perf_counter() - t1
-    del oracle_1t
-    best = min(times)
+        run = lambda a, b, threads, want_map=False: oracle.ssim_f32(a, b, want_map=want_map, fused=True, threads=threads)
+
+    def timed(fn, budget, min_runs=3, max_runs=100000):
+        ts = []
+        stop = time.perf_counter() + budget
+        while (time.perf_counter() < stop or len(ts) < min_runs) and len(ts) < max_runs:
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    W, H = 4096, 4096
+    a, b = oracle.synth_pair(W, H, 0x5EED)
+    v = run(a, b, cores)[0]
+    assert int(np.float32(v).view(np.uint32)) == WORKLOADS["4k"][5][0], "CPU baseline disagrees with the known answer"
+    ts = timed(lambda: run(a, b, cores), budget_s)
+    t1 = timed(lambda: run(a, b, 1), 0.0, min_runs=2)
+    px = W * H
+    per = {"4k": {"pixels": px, "map": False, "threads_all_mpix_s": round(px / min(ts) / 1e6, 1),
+                  "threads_all_median_mpix_s": round(px / statistics.median(ts) / 1e6, 1),
+                  "one_thread_mpix_s": round(px / min(t1) / 1e6, 1)}}
+    # 8192^2 with map (configs[2]) and one 1080p pair (configs[3]'s image); double build: see DESIGN.md (the
+    # reference's fp64 SIMD path is not part of oracle/_ref, so configs[4] has no "reference" CPU number)
+    for name, (w, h, want_map, kat) in (("8k-map", (8192, 8192, True, WORKLOADS["8k-map"][5][0])),
+                                        ("1080p", (1920, 1080, False, WORKLOADS["1080p"][5][0]))):
+        aa, bb = oracle.synth_pair(w, h, 0x5EED)
+        r = run(aa, bb, cores, want_map)
+        assert int(np.float32(r[0]).view(np.uint32)) == kat, "CPU baseline disagrees with the known answer (%s)" % name
+        ta = timed(lambda: run(aa, bb, cores, want_map), 2.0)
+        to = timed(lambda: run(aa, bb, 1, want_map), 0.0, min_runs=2 if name == "1080p" else 1)
+        per[name] = {"pixels": w * h, "map": want_map, "threads_all_mpix_s": round(w * h / min(ta) / 1e6, 1),
+                     "threads_all_median_mpix_s": round(w * h / statistics.median(ta) / 1e6, 1),
+                     "one_thread_mpix_s": round(w * h / min(to) / 1e6, 1)}
+        del aa, bb, r
     model, procs = host_cpu()
-    return {"value": round(W * H / best / 1e6, 1), "unit": "Mpix/s", "cores": cores, "kind": kind,
-            "cpu_model": model, "logical_cpus": procs, "one_thread_mpix_s": round(W * H / t_single / 1e6, 1),
-            "sample": "%d back-to-back runs of one 4096x4096 pair (seed 0x5EED) over ~12 s, best run reported; median %.1f Mpix/s; 1 thread %.1f Mpix/s; %s"
-                      % (len(times), W * H / statistics.median(times) / 1e6, W * H / t_single / 1e6,
+    return {"value": round(px / min(ts) / 1e6, 1), "median": round(px / statistics.median(ts) / 1e6, 1), "unit": "Mpix/s",
+            "cores": cores, "kind": kind, "cpu_model": model, "logical_cpus": procs, "runs": len(ts),
+            "one_thread_mpix_s": per["4k"]["one_thread_mpix_s"], "per_config": per,
+            "sample": "%d back-to-back runs of one 4096x4096 pair (seed 0x5EED, global only) over ~%.0f s on %d threads: value = best run, "
+                      "median = median run; per_config: best of ~2 s (all threads) / of 1-2 runs (1 thread) on one pair of each image size; %s"
+                      % (len(ts), budget_s, cores,
                          "real reference FMA/AVX kernel objects (oracle/_ref) driven by the harness tile loop, OpenMP static schedule"
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
 def measured_traffic(mode, workload, pairs):
-    """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json), scaled to
-    this batch; None when no measurement exists for the configuration."""
+    """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json: rocprofv3 --pmc passes of
+    tools/profile_target.py, FETCH_SIZE/WRITE_SIZE corrected per profiles/r01_fetch_size_calibration.md), scaled
+    from the measured batch to this one; None when no measurement exists for the configuration."""
     key = {"4k": "exact_4096_nomap", "8k-map": "exact_8192_map", "1080p": "exact_1080p_nomap"}.get(workload)
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
@@ -119,17 +201,93 @@ def attainable_hbm_gbs(torch, dev):
     return round(2.0 * n / (best * 1e-3) / 1e9, 1)
 
 
-def host_cpu():
-    model, procs = "unknown", os.cpu_count()
+def kernel_name(mode, variant, want_map):
+    one = mode == 2 or variant == 1
+    return "ssim_strip%d_kernel<%d,%s>" % (1 if one else 2, mode, "true" if want_map else "false")
+
+
+def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
+    """roofline / valu objects of one launch of `pairs` w x h pairs that took kernel_avg_ms."""
+    bpp = 6 if want_map else 2                    # algorithmic HBM bytes per pixel pair (SURVEY.md 8(d))
+    px = float(pairs) * w * h
+    sec = kernel_avg_ms * 1e-3
+    gbs = px * bpp / sec / 1e9
+    ops = VALU_OPS_PER_PIXEL[mode]
+    peak = VALU_PEAK_F64_TOPS if mode == 2 else VALU_PEAK_TOPS
+    t = ops * px / sec / 1e12
+    return ({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+             "algorithmic_bytes_per_launch": px * bpp},
+            {"achieved": round(t, 2), "peak": peak, "unit": "T fp64 lane-ops/s" if mode == 2 else "T lane-ops/s",
+             "frac": round(t / peak, 4), "ops_per_pixel": ops})
+
+
+class Batch(object):
+    """`count` resident synthetic pairs (global seeds first_seed_index + i) and their C-ABI parameter blocks."""
+
+    def __init__(self, torch, ssim_amd, synth, ctx, dev, w, h, first, count, want_map):
+        self.w, self.h, self.count, self.want_map = w, h, count, want_map
+        self.imgs = []
+        self.params = (ssim_amd.Params * max(count, 1))()
+        for i in range(count):
+            # torch owns the memory; the library's own generator (rmgr_ssim_hip_synth_pair_device) fills it on the
+            # context's stream, which is torch's current stream
+            a = torch.empty((h, w), dtype=torch.uint8, device=dev)
+            b = torch.empty((h, w), dtype=torch.uint8, device=dev)
+            ctx.synth_pair(a.data_ptr(), w, b.data_ptr(), w, w, h, synth.BASE_SEED + first + i)
+            m = torch.empty((h, w), dtype=torch.float32, device=dev) if want_map else None
+            self.imgs.append((a, b, m))
+            self.params[i] = ssim_amd.make_params(w, h, a.data_ptr(), 1, w, b.data_ptr(), 1, w, m.data_ptr() if want_map else None, 1, w)
+
+
+def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_map, mode, kats, steps):
+    """One extra BASELINE config on this rank: KAT gate, then `steps` launches timed with HIP events on the launch stream."""
+    batch = Batch(torch, ssim_amd, synth, ctx, dev, w, h, 0, pairs, want_map)
+    sums = torch.zeros(pairs, dtype=torch.float64, device=dev)
+    ctx.set_mode(mode)
     try:
-        with open("/proc/cpuinfo") as f:
-            for l in f:
-                if l.startswith("model name"):
-                    model = l.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return model, procs
+        ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
+        ctx.synchronize()
+        res = ssim_amd.finalize(sums.cpu().numpy(), w, h)
+        gate = "kat"
+        if mode in (0, 3):
+            for i, k in enumerate(kats[:pairs]):
+                if mode == 0 and int(res[i].view(np.uint32)) != k:
+                    raise SystemExit("%s: known-answer check failed: pair %d -> 0x%08x, want 0x%08x" % (name, i, int(res[i].view(np.uint32)), k))
+        elif mode == 1:      # separable: north_star tolerance vs the FMA reference value
+            gate = "|d| <= 1.5e-6 vs the FMA KAT"
+            for i, k in enumerate(kats[:pairs]):
+                ref = float(np.array([k], np.uint32).view(np.float32)[0])
+                if abs(float(res[i]) - ref) > 1.5e-6:
+                    raise SystemExit("%s: fast mode off by %.3g on pair %d" % (name, abs(float(res[i]) - ref), i))
+        else:                # fp64 internals: the naive<double> value, rounded to float
+            gate = "|d| <= 6e-8 vs naive<double>"
+            if (w, h) == (4096, 4096) and abs(float(res[0]) - NAIVE_F64_4K) > 6e-8 + 1e-9:
+                raise SystemExit("%s: double mode off by %.3g" % (name, abs(float(res[0]) - NAIVE_F64_4K)))
+        if want_map:
+            mm = float(batch.imgs[0][2].double().mean().item())
+            if abs(mm - float(res[0])) > 1e-6:
+                raise SystemExit("%s: map mean %.9f disagrees with the global SSIM %.9f" % (name, mm, float(res[0])))
+        for _ in range(2):
+            ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
+        ctx.synchronize()
+        ctx.get_profile()
+        ctx.set_profiling(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
+        ctx.synchronize()
+        wall = time.perf_counter() - t0
+        ctx.set_profiling(False)
+        n, ms = ctx.get_profile()
+    finally:
+        ctx.set_mode(0)
+    k_ms = ms / max(n, 1)
+    roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
+    return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
+            "kernel": kernel_name(mode, 0, want_map), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
+            "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
+            "mpix_s_wall": round(float(pairs) * w * h * steps / wall / 1e6, 1),
+            "roofline": roof, "valu": valu}
 
 
 def main():
@@ -138,35 +296,46 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
-    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (0: the workload's default)")
-    ap.add_argument("--mode", type=int, default=0, help="0 exact (default), 1 fast separable")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (weak) / in total (strong); 0: the workload's default")
+    ap.add_argument("--mode", type=int, default=0, help="0 exact (default), 1 fast separable, 2 double, 3 unfused")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
+    ap.add_argument("--print-launch", action="store_true", help="print the rank launcher command for --gpus N and exit (no GPU needed)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.print_launch:
+        print(" ".join(launcher_command(args.gpus, [a for a in sys.argv[1:] if a != "--print-launch"])))
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])
 
     import numpy as np
     import torch
     import ssim_amd
     from ssim_amd import sharding, synth
 
-    if not os.path.exists(ssim_amd.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import subprocess                       # built artefacts normally travel with the tree; rebuild if they did not
-        subprocess.run(["make", "-C", ROOT, "lib"], check=True, stdout=subprocess.DEVNULL)
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not os.path.exists(ssim_amd.LIB_PATH) and local_rank == 0:
+        subprocess.run(["make", "-C", ROOT, "lib"], check=True, stdout=subprocess.DEVNULL)   # built artefacts normally travel with the tree
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher started a different number of ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no HIP device visible (there is no CPU fallback)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no device: %d visible" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("SSIM_BENCH_FORCE_DIST") == "1":      # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29511))
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     # Everything (torch ops, RCCL, our launches) is ordered on one explicit non-default stream: the legacy
@@ -177,25 +346,24 @@ def main():
     ctx = ssim_amd.Context(local_rank, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
     ctx.set_tuning(args.strip_rows, args.variant)
 
-    global W, H, KAT_PAIR0_HEX, BYTES_PER_PIXEL
-    W, H, default_pairs, want_map, KAT_PAIR0_HEX, workload_desc = WORKLOADS[args.workload]
-    BYTES_PER_PIXEL = 6 if want_map else 2       # + one float per pixel when the map is written
-    P = args.pairs or default_pairs
-    # --- resident synthetic batch: rank r owns global pairs r*P .. r*P+P-1 ---
-    first, _ = sharding.shard_range(rank, world, P)
-    imgs = []
-    params = (ssim_amd.Params * P)()
-    for i in range(P):
-        a, b = synth.pair_torch(W, H, synth.BASE_SEED + first + i, device=dev)
-        m = torch.empty((H, W), dtype=torch.float32, device=dev) if want_map else None
-        imgs.append((a, b, m))
-        params[i] = ssim_amd.make_params(W, H, a.data_ptr(), 1, W, b.data_ptr(), 1, W, m.data_ptr() if want_map else None, 1, W)
-    sums_all = torch.zeros(world * P, dtype=torch.float64, device=dev)       # zero except this rank's slice
+    W, H, weak_pairs, strong_total, want_map, kats, workload_desc = WORKLOADS[args.workload]
+    # --- shard the batch by image: rank r owns global pairs [first, last) ---
+    if args.scaling == "weak":
+        P = args.pairs or weak_pairs
+        first, last = sharding.shard_range(rank, world, P)
+        total = world * P
+    else:
+        total = args.pairs or strong_total
+        first, last = sharding.split_batch(total, world)[rank]
+    mine = last - first
+    batch = Batch(torch, ssim_amd, synth, ctx, dev, W, H, first, mine, want_map)
+    sums_all = torch.zeros(total, dtype=torch.float64, device=dev)       # zero except this rank's slice
     work = torch.zeros_like(sums_all)
     my_slice_ptr = sums_all.data_ptr() + 8 * first
 
     def step():
-        ctx.enqueue_batch(params, P, my_slice_ptr)
+        if mine:
+            ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         # all-reduce of the per-image partial sums; other ranks contribute exact zeros
         return sharding.exchange_sums(sums_all, work, dist)
 
@@ -205,18 +373,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # --- known-answer gate ---
+    # --- known-answer gate: the reference's FMA-path float bits for the first seeds, on whichever rank owns them,
+    #     and (after the exchange) on every rank for the whole vector's plausibility ---
     full = step()
     fence()
     res = ssim_amd.finalize(full.cpu().numpy(), W, H)
-    if int(res[0].view(np.uint32)) != KAT_PAIR0_HEX:
-        raise SystemExit("known-answer check failed: pair 0 -> %r (0x%08x), want 0x%08x" % (float(res[0]), int(res[0].view(np.uint32)), KAT_PAIR0_HEX))
+    if args.mode == 0:
+        for i, k in enumerate(kats):
+            if i < total and int(res[i].view(np.uint32)) != k:
+                raise SystemExit("known-answer check failed on rank %d: pair %d -> %r (0x%08x), want 0x%08x"
+                                 % (rank, i, float(res[i]), int(res[i].view(np.uint32)), k))
     if not np.all(np.isfinite(res)) or res.min() < 0.85 or res.max() > 0.95:
-        raise SystemExit("implausible batch results: %r" % res)
-    if want_map:   # the map that was written must average to the global value
-        mm = float(imgs[0][2].double().mean().item())
-        if abs(mm - float(res[0 if rank == 0 else first])) > 1e-6:
+        raise SystemExit("implausible batch results on rank %d: %r" % (rank, res))
+    if want_map and mine:   # the map that was written must average to the global value
+        mm = float(batch.imgs[0][2].double().mean().item())
+        if abs(mm - float(res[first])) > 1e-6:
             raise SystemExit("map mean %.9f disagrees with the global SSIM" % mm)
+    result_digest = "%016x" % (int(np.bitwise_xor.reduce(res.view(np.uint32).astype(np.uint64) * (np.arange(res.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)))) & 0xFFFFFFFFFFFFFFFF)
 
     # Clock settle (untimed, before the W warm-up steps): the chip takes tens of milliseconds of sustained load
     # to leave its idle DVFS state; a ~1 ms step measured right after the uploads reads up to 20 % slow.
@@ -246,26 +419,29 @@ def main():
 
     # --- the opt-in separable mode on the same batch (kernel time only; never `value`) ---
     other = {}
-    if args.mode == 0:
+    if args.mode == 0 and rank == 0 and mine:
         ctx.set_mode(1)
         for _ in range(2):
-            ctx.enqueue_batch(params, P, my_slice_ptr)
+            ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         ctx.synchronize()
         ctx.set_profiling(True)
         for _ in range(max(args.steps // 2, 3)):
-            ctx.enqueue_batch(params, P, my_slice_ptr)
+            ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         ctx.synchronize()
         n_f, ms_f = ctx.get_profile()
         ctx.set_profiling(False)
         ctx.set_mode(0)
-        other = {"mode": "fast (separable fp32, within tolerance, not bit-identical)", "kernel_avg_ms": round(ms_f / n_f, 4),
-                 "mpix_s": round(float(P) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1)}
-        ctx.enqueue_batch(params, P, my_slice_ptr)
+        roof_f, valu_f = figures(1, mine, W, H, want_map, ms_f / n_f)
+        other = {"mode": "fast (separable fp32, within tolerance, not bit-identical)", "kernel": kernel_name(1, args.variant, want_map),
+                 "kernel_avg_ms": round(ms_f / n_f, 4), "mpix_s": round(float(mine) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1),
+                 "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"]}
+        ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         ctx.synchronize()
 
     # --- single-pair latency/throughput (BASELINE.json configs[1] literally: one pair per call) ---
     single = {}
-    if rank == 0:
+    if rank == 0 and mine:
+        imgs = batch.imgs
         p0 = ssim_amd.make_params(W, H, imgs[0][0].data_ptr(), 1, W, imgs[0][1].data_ptr(), 1, W)   # global-only
         one = (ssim_amd.Params * 1)(p0)
         for _ in range(5):
@@ -283,11 +459,20 @@ def main():
         # the unchanged reference call: HOST pointers, pageable memory, PCIe staging included
         ha, hb = imgs[0][0].cpu().numpy(), imgs[0][1].cpu().numpy()
         hv, _ = ssim_amd.compute_ssim(ha, hb)
-        assert int(hv.view(np.uint32)) == KAT_PAIR0_HEX
+        if args.mode == 0:
+            assert int(hv.view(np.uint32)) == kats[0]
         t1 = time.perf_counter()
         for _ in range(5):
             ssim_amd.compute_ssim(ha, hb)
         dth = (time.perf_counter() - t1) / 5
+        # ... and with the per-pixel map copied back into a caller-owned pageable buffer
+        hmap = np.zeros((H, W), np.float32)
+        hv2, _ = ssim_amd.compute_ssim(ha, hb, out_map=hmap)
+        assert int(hv2.view(np.uint32)) == int(hv.view(np.uint32)) and abs(float(hmap.mean(dtype=np.float64)) - float(hv)) < 1e-6
+        t1 = time.perf_counter()
+        for _ in range(3):
+            ssim_amd.compute_ssim(ha, hb, out_map=hmap)
+        dthm = (time.perf_counter() - t1) / 3
         # a batch of host-resident pairs through the pipelined entry point (PCIe staging overlapped with the kernels)
         nb = max(2, min(8, (256 << 20) // (2 * W * H)))
         hp = [(ha, hb)] * nb
@@ -295,57 +480,75 @@ def main():
         t1 = time.perf_counter()
         hbv = ssim_amd.compute_ssim_batch(hp)
         dtb = (time.perf_counter() - t1) / nb
-        assert int(hbv[0].view(np.uint32)) == KAT_PAIR0_HEX
+        assert int(hbv[0].view(np.uint32)) == int(hv.view(np.uint32))
         single = {"enqueued_ms": round(dt * 1e3, 4), "enqueued_mpix_s": round(W * H / dt / 1e6, 1),
                   "host_batch_pairs": nb, "host_batch_ms_per_pair": round(dtb * 1e3, 3), "host_batch_mpix_s": round(W * H / dtb / 1e6, 1),
                   "blocking_call_ms": round(dts * 1e3, 4), "blocking_call_mpix_s": round(W * H / dts / 1e6, 1),
-                  "host_pointer_call_ms": round(dth * 1e3, 3), "host_pointer_call_mpix_s": round(W * H / dth / 1e6, 1)}
-        ctx.enqueue_batch(params, P, my_slice_ptr)      # restore the slice for consistency
+                  "host_pointer_call_ms": round(dth * 1e3, 3), "host_pointer_call_mpix_s": round(W * H / dth / 1e6, 1),
+                  "host_pointer_call_with_map_ms": round(dthm * 1e3, 3), "host_pointer_call_with_map_mpix_s": round(W * H / dthm / 1e6, 1)}
+        del hmap, ha, hb
+        ctx.enqueue_batch(batch.params, mine, my_slice_ptr)      # restore the slice for consistency
         torch.cuda.synchronize()
+
+    # --- the other BASELINE configs, rank 0 only, after the timed region (kernel time from HIP events) ---
+    configs = {}
+    if rank == 0 and not args.no_configs and args.mode == 0 and args.variant == 0 and args.strip_rows == 0:
+        del batch                                  # free the headline batch first
+        torch.cuda.empty_cache()
+        ksteps = max(args.steps // 2, 5)
+        w8, h8 = 8192, 8192
+        configs["8k-map exact"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "8k-map exact", w8, h8, 2, True, 0, WORKLOADS["8k-map"][5], ksteps)
+        configs["8k-map fast"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "8k-map fast", w8, h8, 2, True, 1, WORKLOADS["8k-map"][5], ksteps)
+        configs["1080p x128 exact"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "1080p exact", 1920, 1080, 128, False, 0, WORKLOADS["1080p"][5], ksteps)
+        configs["1080p x128 fast"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "1080p fast", 1920, 1080, 128, False, 1, WORKLOADS["1080p"][5], ksteps)
+        configs["4k double + map"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "4k double", 4096, 4096, 4, True, 2, WORKLOADS["4k"][5], ksteps)
+        configs["4k x1 exact"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "4k single", 4096, 4096, 1, False, 0, WORKLOADS["4k"][5], 50)
 
     attainable = None
     if rank == 0:
         attainable = attainable_hbm_gbs(torch, dev)
     if rank == 0:
-        pixels = float(world) * P * W * H * args.steps
+        pixels = float(total) * W * H * args.steps
         value = pixels / elapsed / 1e6
-        bytes_per_launch = float(P) * W * H * BYTES_PER_PIXEL
-        achieved = bytes_per_launch / (kernel_avg_ms * 1e-3) / 1e9
-        ops_px = VALU_OPS_PER_PIXEL if args.mode in (0, 3) else 133      # separable: 5 x 22 blur + 23
-        valu = ops_px * float(P) * W * H / (kernel_avg_ms * 1e-3) / 1e12
+        roof, valu = figures(args.mode, mine, W, H, want_map, kernel_avg_ms) if mine else ({}, {})
+        if roof:
+            roof.update({"traffic": measured_traffic(args.mode, args.workload, mine),
+                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes committed under profiles/ (traffic.json), scaled to this batch; null if unmeasured",
+                         "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
+                         "kernel": kernel_name(args.mode, args.variant, want_map), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
+                         "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
+            valu.update({"measured_peak": VALU_MEASURED_PEAK_TOPS, "frac_of_measured_peak": round(valu["achieved"] / VALU_MEASURED_PEAK_TOPS, 4),
+                         "measured_peak_at_kernel_occupancy": VALU_MEASURED_2WAVE_TOPS,
+                         "frac_of_peak_at_kernel_occupancy": round(valu["achieved"] / VALU_MEASURED_2WAVE_TOPS, 4)})
         line = {
             "metric": "Mpix/s (global SSIM, no map) on 4K pairs; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d pairs per GPU per step, sharded by image, %s"
-                                   % (workload_desc, P, "RCCL all-reduce of per-image fp64 sums per step" if world > 1 else "single GPU, no collective"),
-                       "name": args.workload,
-                       "mode": ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double", "unfused"][args.mode],
-                       "pairs_per_gpu": P, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.mode, args.workload, P),
-                         "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
-                         "kernel": "ssim_strip1_kernel" if (args.mode == 2 or args.variant == 1) else "ssim_strip2_kernel", "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"},
-            "valu": {"achieved": round(valu, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(valu / VALU_PEAK_TOPS, 4),
-                     "ops_per_pixel": ops_px, "measured_peak": VALU_MEASURED_PEAK_TOPS,
-                     "frac_of_measured_peak": round(valu / VALU_MEASURED_PEAK_TOPS, 4),
-                     "measured_peak_at_kernel_occupancy": VALU_MEASURED_2WAVE_TOPS,
-                     "frac_of_peak_at_kernel_occupancy": round(valu / VALU_MEASURED_2WAVE_TOPS, 4)},
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64" if args.mode == 2 else "f32", "data": "synthetic",
+            "config": {"workload": "%s, %s, sharded by image, %s"
+                                   % (workload_desc,
+                                      "%d pairs per GPU per step" % mine if args.scaling == "weak" else "%d pairs in total split over %d GPUs (%d on rank 0)" % (total, world, mine),
+                                      "RCCL all-reduce of per-image fp64 sums per step" if world > 1 else "single GPU, no collective"),
+                       "name": args.workload, "mode": MODE_NAMES[args.mode],
+                       "pairs_per_gpu": mine, "pairs_total": total, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant,
+                       "results_digest": result_digest},
+            "roofline": roof,
+            "valu": valu,
             "single_pair": single,
             "fast_mode": other,
+            "configs": configs,
             "device": ctx.describe(),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
+        sys.stdout.flush()
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -165,6 +165,16 @@ rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* ctx, void* hostPtr,
 rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* ctx, rmgr_int32_t enabled) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* ctx, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT;
 
+/*
+ * The synthetic test pattern the benchmark and the self-tests run on (no reference counterpart: the reference's
+ * tests read image files), generated in device memory, asynchronously on the context's stream:
+ *   r = splitmix64(seed ^ ((y << 32) | x));  g = ((3x + 5y) >> 2) & 255;  A = (3g + (r & 255)) >> 2;
+ *   B = clamp(A + ((r >> 8) % 33) - 16, 0, 255)          planar, one byte per pixel, rows stride bytes apart.
+ * Known answers: seed 0x5EED gives A[0][0..3] = 45, 59, 51, 6 and B[0][0..3] = 51, 58, 48, 5.
+ */
+rmgr_int32_t rmgr_ssim_hip_synth_pair_device(rmgr_ssim_hip_Context* ctx, rmgr_uint8_t* imgA, ptrdiff_t strideA, rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                             rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint64_t seed) RMGR_NOEXCEPT;
+
 /* Human-readable description of the device and build ("gfx950 ... CUs ..."); static storage. */
 const char* rmgr_ssim_hip_describe(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 

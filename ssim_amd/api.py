@@ -68,6 +68,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
+    "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
@@ -121,6 +122,7 @@ def load_library(path=None):
         "rmgr_ssim_hip_compute_ssim_channels_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
         "rmgr_ssim_hip_compute_ssim_luminance_host": [vp, ctypes.POINTER(ctypes.c_float), vp, c_pd, vp, c_pd, u32, u32, u32, vp],
         "rmgr_ssim_hip_luminance_device": [vp, vp, c_pd, vp, c_pd, c_pd, u32, u32],
+        "rmgr_ssim_hip_synth_pair_device": [vp, vp, c_pd, vp, c_pd, u32, u32, ctypes.c_uint64],
         "rmgr_ssim_hip_comm_get_unique_id": [ctypes.c_char_p],
         "rmgr_ssim_hip_comm_init": [vp, ctypes.c_char_p, i32, i32],
         "rmgr_ssim_hip_comm_allreduce_sums": [vp, vp, u32],
@@ -310,6 +312,12 @@ class Context(object):
         arr = np.ascontiguousarray(arr)
         return self.alloc(arr.nbytes).upload(arr)
 
+    def download(self, ptr, dtype, shape):
+        """Copy device memory at `ptr` into a new numpy array (blocking)."""
+        out = np.empty(shape, dtype)
+        _check("rmgr_ssim_hip_memcpy_d2h", self.lib.rmgr_ssim_hip_memcpy_d2h(self.handle, out.ctypes.data, ptr, out.nbytes))
+        return out
+
     def synchronize(self):
         _check("rmgr_ssim_hip_synchronize", self.lib.rmgr_ssim_hip_synchronize(self.handle))
 
@@ -341,6 +349,11 @@ class Context(object):
 
     def comm_allreduce_sums(self, sums_dev_ptr, count):
         _check("rmgr_ssim_hip_comm_allreduce_sums", self.lib.rmgr_ssim_hip_comm_allreduce_sums(self.handle, sums_dev_ptr, count))
+
+    def synth_pair(self, a_ptr, a_stride, b_ptr, b_stride, width, height, seed):
+        """Fill two device planes with the synthetic pair of SURVEY.md 8(d) (asynchronous on the context's stream)."""
+        _check("rmgr_ssim_hip_synth_pair_device", self.lib.rmgr_ssim_hip_synth_pair_device(
+            self.handle, a_ptr, a_stride, b_ptr, b_stride, width, height, seed))
 
     def set_profiling(self, on):
         _check("rmgr_ssim_hip_set_profiling", self.lib.rmgr_ssim_hip_set_profiling(self.handle, 1 if on else 0))

@@ -14,8 +14,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 using ssim_hip::PairDesc;
@@ -31,7 +33,18 @@ struct rmgr_ssim_hip_Context_ {
 
     // grow-only device scratch
     double*   partials;     size_t partials_cap;   // doubles
-    PairDesc* descs;        size_t descs_cap;      // entries
+    // Batch descriptor tables: a small ring of (device table, pinned mirror, "last launch that read it" event), so
+    // that enqueueing a DIFFERENT batch never waits for the stream -- only for the launch kDescSlots enqueues ago --
+    // and a serving loop that alternates between a few batches re-uses their uploaded tables.
+    enum { kDescSlots = 4 };
+    struct DescSlot {
+        PairDesc* dev;  size_t dev_cap;     // entries
+        PairDesc* host; size_t host_cap;    // pinned mirror of what `dev` holds (or will hold once the queued copy ran)
+        size_t    live;                     // entries of `host`/`dev` that are valid (0: nothing uploaded)
+        hipEvent_t used;                    // recorded after the last launch reading `dev`
+        bool      in_flight;
+    } desc_slots[kDescSlots];
+    int       desc_next;
     uint8_t*  stage_a;      size_t stage_a_cap;    // bytes (host-pointer path)
     uint8_t*  stage_b;      size_t stage_b_cap;
     float*    stage_map;    size_t stage_map_cap;  // floats
@@ -43,11 +56,13 @@ struct rmgr_ssim_hip_Context_ {
     double*   batch_sums;   size_t batch_sums_cap;
     hipStream_t copy_stream;
     hipEvent_t  slot_copied[2], slot_done[2];
+    // banded single-pair host calls: a third stream for the map on its way back, per-band events
+    enum { kMaxBands = 16 };
+    hipStream_t out_stream;
+    hipEvent_t  band_copied[kMaxBands], band_done[kMaxBands];
     uint8_t*  h_stage;      size_t h_stage_cap;    // bytes: small image pairs are gathered here for one DMA
     float*    h_map[2];     size_t h_map_cap[2];   // floats: bounce buffers for the map copy-back
     hipEvent_t map_ev[2];
-    PairDesc* h_descs;      size_t h_descs_cap;
-    size_t    descs_live;   // entries of `descs` that mirror h_descs (0: nothing uploaded)
 
     bool profiling;
     std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;   // recorded, not yet read
@@ -82,6 +97,24 @@ int map_hip_error(hipError_t e)
 }
 
 #define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (void)hipGetLastError(); return map_hip_error(e_); } } while (0)
+
+// Entry points run on the context's device WITHOUT changing the calling thread's current device (the reference API
+// has no such side effect): the previous device is restored on every exit path.
+struct DeviceGuard {
+    int prev, rc;
+    bool restore;
+    explicit DeviceGuard(int dev) : prev(-1), rc(0), restore(false)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev != dev) {
+            const hipError_t e = hipSetDevice(dev);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); return; }
+            restore = prev >= 0;
+        }
+    }
+    ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
+};
+#define USE_DEVICE(c) DeviceGuard device_guard_((c)->device); if (device_guard_.rc) return device_guard_.rc
 
 template <typename T>
 int grow_device(T*& ptr, size_t& cap, size_t need)
@@ -123,67 +156,119 @@ void extent(const rmgr_ssim_ImgParams& im, uint32_t w, uint32_t h, int64_t& lo, 
     hi = (dx > 0 ? dx : 0) + (dy > 0 ? dy : 0);
 }
 
-int record_begin(rmgr_ssim_hip_Context* c, hipEvent_t& b, hipEvent_t& e)
+// Event pair for timing one launch (NULLs when profiling is off).  The pair enters `pending` only after BOTH events
+// were recorded (commit_events); a launch that fails, or launches nothing, hands it back (release_events).
+int acquire_events(rmgr_ssim_hip_Context* c, hipEvent_t& b, hipEvent_t& e)
 {
     b = e = NULL;
     if (!c->profiling) return 0;
     if (!c->free_events.empty()) {
         b = c->free_events.back().first; e = c->free_events.back().second;
         c->free_events.pop_back();
-    } else {
-        HIP_TRY(hipEventCreate(&b));
-        HIP_TRY(hipEventCreate(&e));
+        return 0;
     }
-    try { c->pending.push_back(std::make_pair(b, e)); }
-    catch (...) { (void)hipEventDestroy(b); (void)hipEventDestroy(e); b = e = NULL; return ENOMEM; }
+    HIP_TRY(hipEventCreate(&b));
+    hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(b); b = e = NULL; return map_hip_error(err); }
     return 0;
 }
 
+void release_events(rmgr_ssim_hip_Context* c, hipEvent_t b, hipEvent_t e)
+{
+    if (!b) return;
+    try { c->free_events.push_back(std::make_pair(b, e)); }
+    catch (...) { (void)hipEventDestroy(b); (void)hipEventDestroy(e); }
+}
+
+int commit_events(rmgr_ssim_hip_Context* c, hipEvent_t b, hipEvent_t e)
+{
+    if (!b) return 0;
+    try { c->pending.push_back(std::make_pair(b, e)); }
+    catch (...) { (void)hipEventDestroy(b); (void)hipEventDestroy(e); return ENOMEM; }
+    return 0;
+}
+
+// Reads every pending pair.  A pair that cannot be read is dropped (its events recycled) and reported once; the
+// pairs before and after it are counted exactly once.
 int drain_profile(rmgr_ssim_hip_Context* c)
 {
+    int rc = 0;
     for (size_t i = 0; i < c->pending.size(); ++i) {
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(c->pending[i].second));
-        HIP_TRY(hipEventElapsedTime(&ms, c->pending[i].first, c->pending[i].second));
-        c->prof_ms += ms;
-        c->prof_launches += 1;
-        try { c->free_events.push_back(c->pending[i]); }
-        catch (...) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
+        hipError_t err = hipEventSynchronize(c->pending[i].second);
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, c->pending[i].first, c->pending[i].second);
+        if (err == hipSuccess) {
+            c->prof_ms += ms;
+            c->prof_launches += 1;
+        } else {
+            (void)hipGetLastError();
+            if (!rc) rc = map_hip_error(err);
+        }
+        release_events(c, c->pending[i].first, c->pending[i].second);
     }
     c->pending.clear();
+    return rc;
+}
+
+// Device copy of a batch's descriptor table: re-used when any ring slot already holds exactly these descriptors,
+// otherwise uploaded into the next slot (waiting, at most, for the launch that read that slot kDescSlots batches ago).
+int upload_descs(rmgr_ssim_hip_Context* c, const PairDesc* descs, uint32_t count, int& slot_out)
+{
+    typedef rmgr_ssim_hip_Context_::DescSlot Slot;
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
+        Slot& s = c->desc_slots[i];
+        if (s.live == count && memcmp(s.host, descs, sizeof(PairDesc) * count) == 0) { slot_out = i; return 0; }
+    }
+    const int k = c->desc_next;
+    c->desc_next = (k + 1) % rmgr_ssim_hip_Context_::kDescSlots;
+    Slot& s = c->desc_slots[k];
+    if (s.in_flight) { HIP_TRY(hipEventSynchronize(s.used)); s.in_flight = false; }
+    s.live = 0;
+    int rc;
+    if ((rc = grow_device(s.dev, s.dev_cap, count))) return rc;
+    if ((rc = grow_pinned(s.host, s.host_cap, count))) return rc;
+    if (!s.used) HIP_TRY(hipEventCreateWithFlags(&s.used, hipEventDisableTiming));
+    memcpy(s.host, descs, sizeof(PairDesc) * count);
+    HIP_TRY(hipMemcpyAsync(s.dev, s.host, sizeof(PairDesc) * count, hipMemcpyHostToDevice, c->stream));
+    s.live = count;
+    slot_out = k;
     return 0;
 }
 
 // Enqueue kernel + reduction for `count` pairs whose descriptors are in `descs` (host).
-int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev)
+// y_begin / y_rows / reduce: the row window of this launch (ssim_kernels.h plan()); the default is the whole image.
+int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev,
+            uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu, bool reduce = true)
 {
     int variant = c->variant;
     for (uint32_t i = 0; i < count && variant != 1; ++i)
         if (!ssim_hip::fits_strip2(descs[i], width, height)) variant = 1;
-    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count);
-    int rc = grow_device(c->partials, c->partials_cap, (size_t)count * geo.partials_per_image() + 1);
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
+    int rc = grow_device(c->partials, c->partials_cap, ssim_hip::partials_size(geo));
     if (rc) return rc;
     PairDesc single = descs[0];
     const PairDesc* descs_dev = NULL;
+    int slot = -1;
     if (count > 1) {
-        // Re-enqueueing the same batch (the steady state of a serving loop) reuses the uploaded
-        // descriptor table; a different batch waits for the stream before the pinned mirror and
-        // the device table are overwritten.
-        if (!(c->descs_live == count && memcmp(c->h_descs, descs, sizeof(PairDesc) * count) == 0)) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->descs_live = 0;
-            if ((rc = grow_device(c->descs, c->descs_cap, count))) return rc;
-            if ((rc = grow_pinned(c->h_descs, c->h_descs_cap, count))) return rc;
-            memcpy(c->h_descs, descs, sizeof(PairDesc) * count);
-            HIP_TRY(hipMemcpyAsync(c->descs, c->h_descs, sizeof(PairDesc) * count, hipMemcpyHostToDevice, c->stream));
-            c->descs_live = count;
-        }
-        descs_dev = c->descs;
+        if ((rc = upload_descs(c, descs, count, slot))) return rc;
+        descs_dev = c->desc_slots[slot].dev;
         if (any_map && !single.map) single.map = reinterpret_cast<float*>(1);  // only its non-NULLness is used
     }
-    hipEvent_t eb, ee;
-    if ((rc = record_begin(c, eb, ee))) return rc;
-    HIP_TRY(ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee));
+    const bool launches_kernel = count > 0 && geo.strips_x > 0 && geo.strips_y > 0;
+    hipEvent_t eb = NULL, ee = NULL;
+    if (launches_kernel && (rc = acquire_events(c, eb, ee))) return rc;
+    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee, reduce);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        release_events(c, eb, ee);
+        if (slot >= 0) { (void)hipStreamSynchronize(c->stream); c->desc_slots[slot].live = 0; }   // the table upload may still be queued
+        return map_hip_error(err);
+    }
+    if ((rc = commit_events(c, eb, ee))) return rc;
+    if (slot >= 0) {
+        HIP_TRY(hipEventRecord(c->desc_slots[slot].used, c->stream));
+        c->desc_slots[slot].in_flight = true;
+    }
     return 0;
 }
 
@@ -201,6 +286,171 @@ PairDesc make_desc(const rmgr_ssim_Params& p)
 float mean_of(double sum, uint32_t width, uint32_t height)
 {
     return float(sum / double(uint32_t(width * height)));   // src/ssim.cpp:1102 (32-bit product kept)
+}
+
+// ---- the per-pixel map on its way back to the caller (host-pointer entry points) ----
+
+// Rows [y0, y1) of the dense device map (c->stage_map, W floats per row) into the caller's map, any ssimStep /
+// ssimStride.  Unit step and a positive stride: the DMA engine writes the caller's rows directly (one 2-D copy).
+// Anything else: through two pinned bounce buffers in chunks, the CPU scattering chunk k-1 while chunk k is in
+// flight.  Returns after the rows are in the caller's memory.
+int map_rows_to_host(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, uint32_t y0, uint32_t y1, hipStream_t stream)
+{
+    const uint32_t W = p.width;
+    if (y1 <= y0 || W == 0) return 0;
+    const float* src = c->stage_map + (size_t)y0 * W;
+    if (p.ssimStep == 1 && p.ssimStride >= (ptrdiff_t)W) {
+        float* dst = p.ssimMap + (ptrdiff_t)y0 * p.ssimStride;
+        if (p.ssimStride == (ptrdiff_t)W)
+            HIP_TRY(hipMemcpyAsync(dst, src, sizeof(float) * (size_t)(y1 - y0) * W, hipMemcpyDeviceToHost, stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(dst, sizeof(float) * (size_t)p.ssimStride, src, sizeof(float) * W, sizeof(float) * W, y1 - y0, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int rc;
+    const size_t rowsPerChunk = std::max<size_t>(1, (size_t(8) << 20) / (sizeof(float) * W));
+    const size_t chunkFloats = rowsPerChunk * W;
+    if ((rc = grow_pinned(c->h_map[0], c->h_map_cap[0], chunkFloats))) return rc;
+    if ((rc = grow_pinned(c->h_map[1], c->h_map_cap[1], chunkFloats))) return rc;
+    for (int i = 0; i < 2; ++i)
+        if (!c->map_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->map_ev[i], hipEventDisableTiming));
+    const size_t total = y1 - y0, chunks = (total + rowsPerChunk - 1) / rowsPerChunk;
+    for (size_t k = 0; k <= chunks; ++k) {
+        if (k < chunks) {
+            const size_t r0 = k * rowsPerChunk, rows = std::min(rowsPerChunk, total - r0);
+            HIP_TRY(hipMemcpyAsync(c->h_map[k & 1], src + r0 * W, sizeof(float) * rows * W, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipEventRecord(c->map_ev[k & 1], stream));
+        }
+        if (k > 0) {
+            const size_t j = k - 1, r0 = j * rowsPerChunk, rows = std::min(rowsPerChunk, total - r0);
+            HIP_TRY(hipEventSynchronize(c->map_ev[j & 1]));
+            const float* from = c->h_map[j & 1];
+            for (size_t y = 0; y < rows; ++y, from += W) {
+                float* row = p.ssimMap + (ptrdiff_t)(y0 + r0 + y) * p.ssimStride;
+                if (p.ssimStep == 1) memcpy(row, from, sizeof(float) * W);
+                else for (uint32_t x = 0; x < W; ++x) row[(ptrdiff_t)x * p.ssimStep] = from[x];
+            }
+        }
+    }
+    return 0;
+}
+
+// Rows of both images occupy disjoint byte ranges (no column-major or otherwise row-interleaved layout), and the
+// image is tall enough to be worth cutting: the precondition of the banded pipeline.
+bool bandable(const rmgr_ssim_Params& p)
+{
+    if (p.height < 256 || p.width == 0) return false;
+    const rmgr_ssim_ImgParams* im[2] = {&p.imgA, &p.imgB};
+    for (int i = 0; i < 2; ++i) {
+        const int64_t span = (int64_t)(p.width - 1) * (im[i]->step < 0 ? -(int64_t)im[i]->step : (int64_t)im[i]->step) + 1;
+        const int64_t stride = im[i]->stride < 0 ? -(int64_t)im[i]->stride : (int64_t)im[i]->stride;
+        if (stride < span) return false;
+    }
+    return true;
+}
+
+// Byte range [lo, hi] (relative to topLeft) of rows [r0, r1) of a row-separable image.
+void rows_extent(const rmgr_ssim_ImgParams& im, uint32_t w, uint32_t r0, uint32_t r1, int64_t& lo, int64_t& hi)
+{
+    const int64_t dx = (int64_t)(w - 1) * (int64_t)im.step;
+    const int64_t ya = (int64_t)r0 * (int64_t)im.stride, yb = (int64_t)(r1 - 1) * (int64_t)im.stride;
+    lo = std::min(ya, yb) + (dx < 0 ? dx : 0);
+    hi = std::max(ya, yb) + (dx > 0 ? dx : 0);
+}
+
+// The banded pipeline of one large host pair with a map (see the call site).  `dev`/`d` address the staged device
+// copies (not yet filled), loA/loB are the byte offsets of the images' lowest addresses relative to topLeft.
+int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rmgr_ssim_Params& dev, const PairDesc& d, int64_t loA, int64_t loB)
+{
+    (void)dev;
+    const uint32_t W = p.width, H = p.height;
+    int bands = 4;
+    if (const char* e = getenv("RMGR_SSIM_HIP_BANDS")) bands = atoi(e);
+    bands = std::max(1, std::min<int>(bands, rmgr_ssim_hip_Context_::kMaxBands));
+    uint32_t band_rows = ((H + bands - 1) / bands + 7u) & ~7u;
+    if (band_rows < 64) band_rows = 64;
+    const int n = (int)((H + band_rows - 1) / band_rows);
+    if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->out_stream) HIP_TRY(hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking));
+    for (int k = 0; k < n; ++k) {
+        if (!c->band_copied[k]) HIP_TRY(hipEventCreateWithFlags(&c->band_copied[k], hipEventDisableTiming));
+        if (!c->band_done[k]) HIP_TRY(hipEventCreateWithFlags(&c->band_done[k], hipEventDisableTiming));
+    }
+    // input chunk k = rows [in[k], in[k+1]); once it has landed, output rows [out[k], out[k+1]) can be computed:
+    // everything up to 8 rows (>= the 5 halo rows, and a whole reduction cell) short of the rows present.
+    uint32_t in[rmgr_ssim_hip_Context_::kMaxBands + 1], out[rmgr_ssim_hip_Context_::kMaxBands + 1];
+    for (int k = 0; k <= n; ++k) {
+        in[k] = std::min<uint64_t>((uint64_t)k * band_rows, H);
+        out[k] = (k == 0) ? 0 : (k == n ? H : in[k] - 8);
+    }
+
+    // The helper thread returns band k's map rows while the caller's thread feeds bands k+1, k+2, ...
+    struct Shared {
+        std::mutex m; std::condition_variable cv;
+        int launched; bool abort; int rc;
+    } sh;
+    sh.launched = 0; sh.abort = false; sh.rc = 0;
+    struct Worker {
+        rmgr_ssim_hip_Context* c; const rmgr_ssim_Params* p; Shared* sh; const uint32_t* out; int n;
+        void operator()() const
+        {
+            int rc = 0;
+            if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); rc = ENODEV; }
+            for (int k = 0; k < n && rc == 0; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(sh->m);
+                    sh->cv.wait(lk, [&] { return sh->launched > k || sh->abort; });
+                    if (sh->launched <= k) break;            // aborted before band k was launched
+                }
+                const hipError_t e = hipEventSynchronize(c->band_done[k]);
+                if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); break; }
+                rc = map_rows_to_host(c, *p, out[k], out[k + 1], c->out_stream);
+            }
+            std::lock_guard<std::mutex> lk(sh->m);
+            if (rc && !sh->rc) sh->rc = rc;
+        }
+    };
+    const Worker work = {c, &p, &sh, out, n};
+    std::thread helper;
+    bool threaded = true;
+    try { helper = std::thread(work); } catch (...) { threaded = false; }
+
+    int rc = 0;
+    const rmgr_ssim_ImgParams* img[2] = {&p.imgA, &p.imgB};
+    uint8_t* stage[2] = {c->stage_a, c->stage_b};
+    const int64_t lo_img[2] = {loA, loB};
+    for (int k = 0; k < n && rc == 0; ++k) {
+        for (int j = 0; j < 2 && rc == 0; ++j) {
+            int64_t lo, hi;
+            rows_extent(*img[j], W, in[k], in[k + 1], lo, hi);
+            const hipError_t e = hipMemcpyAsync(stage[j] + (lo - lo_img[j]), img[j]->topLeft + lo, (size_t)(hi - lo + 1), hipMemcpyHostToDevice, c->copy_stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+        }
+        hipError_t e = rc ? hipSuccess : hipEventRecord(c->band_copied[k], c->copy_stream);
+        if (!rc && e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->band_copied[k], 0);
+        if (!rc && e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+        if (!rc && out[k + 1] > out[k])
+            rc = enqueue(c, W, H, 1, &d, true, c->h_sums, out[k], out[k + 1] - out[k], k == n - 1);
+        if (!rc) {
+            e = hipEventRecord(c->band_done[k], c->stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+        }
+        if (!rc) {
+            { std::lock_guard<std::mutex> lk(sh.m); sh.launched = k + 1; }
+            sh.cv.notify_one();
+        }
+    }
+    if (rc) {
+        { std::lock_guard<std::mutex> lk(sh.m); sh.abort = true; }
+        sh.cv.notify_one();
+    }
+    if (threaded) helper.join();
+    else if (!rc) work();                         // no thread could be started: the same steps, serially
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = map_hip_error(e); }
+    (void)hipStreamSynchronize(c->copy_stream);
+    return rc ? rc : sh.rc;
 }
 
 rmgr_ssim_hip_Context* g_default = NULL;
@@ -245,7 +495,8 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ENODEV; }
     if (device < 0 || device >= n) return EINVAL;
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard device_guard_(device);
+    if (device_guard_.rc) return device_guard_.rc;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     rmgr_ssim_hip_Context* c = new (std::nothrow) rmgr_ssim_hip_Context_();
@@ -258,7 +509,8 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->strip_rows = 0;
     c->variant = 0;
     c->partials = NULL; c->partials_cap = 0;
-    c->descs = NULL; c->descs_cap = 0;
+    memset(c->desc_slots, 0, sizeof(c->desc_slots));
+    c->desc_next = 0;
     c->stage_a = NULL; c->stage_a_cap = 0;
     c->stage_b = NULL; c->stage_b_cap = 0;
     c->stage_map = NULL; c->stage_map_cap = 0;
@@ -267,8 +519,8 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     for (int i = 0; i < 2; ++i) { c->slot_dev[i] = c->slot_pin[i] = NULL; c->slot_dev_cap[i] = c->slot_pin_cap[i] = 0; c->slot_copied[i] = c->slot_done[i] = NULL; }
     c->batch_sums = NULL; c->batch_sums_cap = 0;
     c->copy_stream = NULL;
-    c->h_descs = NULL; c->h_descs_cap = 0;
-    c->descs_live = 0;
+    c->out_stream = NULL;
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kMaxBands; ++i) c->band_copied[i] = c->band_done[i] = NULL;
     c->h_map[0] = c->h_map[1] = NULL; c->h_map_cap[0] = c->h_map_cap[1] = 0;
     c->map_ev[0] = c->map_ev[1] = NULL;
     c->comm = NULL;
@@ -289,13 +541,17 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
 rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
-    (void)hipSetDevice(c->device);
+    DeviceGuard device_guard_(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)rmgr_ssim_hip_comm_destroy(c);
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
-    if (c->descs) (void)hipFree(c->descs);
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
+        if (c->desc_slots[i].dev) (void)hipFree(c->desc_slots[i].dev);
+        if (c->desc_slots[i].host) (void)hipHostFree(c->desc_slots[i].host);
+        if (c->desc_slots[i].used) (void)hipEventDestroy(c->desc_slots[i].used);
+    }
     if (c->stage_a) (void)hipFree(c->stage_a);
     if (c->stage_b) (void)hipFree(c->stage_b);
     if (c->stage_map) (void)hipFree(c->stage_map);
@@ -309,7 +565,11 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     }
     if (c->batch_sums) (void)hipFree(c->batch_sums);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->h_descs) (void)hipHostFree(c->h_descs);
+    if (c->out_stream) (void)hipStreamDestroy(c->out_stream);
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kMaxBands; ++i) {
+        if (c->band_copied[i]) (void)hipEventDestroy(c->band_copied[i]);
+        if (c->band_done[i]) (void)hipEventDestroy(c->band_done[i]);
+    }
     for (int i = 0; i < 2; ++i) { if (c->h_map[i]) (void)hipHostFree(c->h_map[i]); if (c->map_ev[i]) (void)hipEventDestroy(c->map_ev[i]); }
     if (c->owns_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -363,7 +623,7 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t
     }
     for (uint32_t i = 0; i < count; ++i)
         if (any_map && params[i].ssimMap == NULL) return EINVAL;   // all or none
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     // One launch covers up to 65535 pairs (grid.z); larger batches go out in consecutive launches.
     const uint32_t kMaxPerLaunch = 65535;
     PairDesc* descs = new (std::nothrow) PairDesc[std::min(kMaxPerLaunch, count)];
@@ -394,7 +654,7 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* c, rmg
         if (!c) return ENODEV;
         guard = std::unique_lock<std::mutex>(c->lock);
     }
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     const uint32_t W = params[0].width, H = params[0].height;
     if (W == 0 || H == 0) {                       // 0/0, like the single call
         for (uint32_t i = 0; i < count; ++i) ssim[i] = mean_of(0.0, W, H);
@@ -479,7 +739,7 @@ rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmg
 rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -489,7 +749,7 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* c, float* 
     if (!c) return EINVAL;
     int rc = validate(ssim, params, NULL);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     // The reduction kernel stores the sum straight into pinned host memory (mapped into the device's address
     // space): no device-to-host copy call on the latency path, just the stream synchronisation.
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
@@ -513,7 +773,7 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
         if (!c) return ENODEV;
         guard = std::unique_lock<std::mutex>(c->lock);
     }
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     const uint32_t W = params->width, H = params->height;
 
     // The reference allocates its tile scratch through params->alloc exactly once and fails with
@@ -531,9 +791,10 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     (void)rel;
 
     rmgr_ssim_Params dev = *params;
+    bool staged = true;                  // false: the large-image copies are still to be issued
+    int64_t loA = 0, hiA = 0, loB = 0, hiB = 0;
     if (W && H) {
         // Stage the byte range each image occupies; step/stride semantics carry over unchanged.
-        int64_t loA, hiA, loB, hiB;
         extent(params->imgA, W, H, loA, hiA);
         extent(params->imgB, W, H, loB, hiB);
         const size_t nA = (size_t)(hiA - loA + 1), nB = (size_t)(hiB - loB + 1);
@@ -551,10 +812,9 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
         } else {
             if ((rc = grow_device(c->stage_a, c->stage_a_cap, nA))) return rc;
             if ((rc = grow_device(c->stage_b, c->stage_b_cap, nB))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->stage_a, params->imgA.topLeft + loA, nA, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(c->stage_b, params->imgB.topLeft + loB, nB, hipMemcpyHostToDevice, c->stream));
             dev.imgA.topLeft = c->stage_a - loA;
             dev.imgB.topLeft = c->stage_b - loB;
+            staged = false;                   // copied below: in one piece, or band by band
         }
         if (params->ssimMap) {
             if ((rc = grow_device(c->stage_map, c->stage_map_cap, (size_t)W * H))) return rc;
@@ -568,37 +828,23 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
 
     if ((rc = grow_pinned(c->h_sums, c->h_sums_cap, 1))) return rc;
     const PairDesc d = make_desc(dev);
-    if ((rc = enqueue(c, W, H, 1, &d, d.map != NULL, c->h_sums))) return rc;      // sum lands in pinned host memory
 
-    if (params->ssimMap && W && H) {
-        // Map back to the caller's (pageable) buffer: D2H into two pinned bounce buffers in row
-        // chunks, the CPU scatters chunk k-1 into ssimStep/ssimStride layout while chunk k is in flight.
-        const size_t rowsPerChunk = std::max<size_t>(1, (size_t(8) << 20) / (sizeof(float) * W));
-        const size_t chunkFloats = rowsPerChunk * W;
-        if ((rc = grow_pinned(c->h_map[0], c->h_map_cap[0], chunkFloats))) return rc;
-        if ((rc = grow_pinned(c->h_map[1], c->h_map_cap[1], chunkFloats))) return rc;
-        for (int i = 0; i < 2; ++i)
-            if (!c->map_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->map_ev[i], hipEventDisableTiming));
-        const size_t chunks = (H + rowsPerChunk - 1) / rowsPerChunk;
-        for (size_t k = 0; k <= chunks; ++k) {
-            if (k < chunks) {
-                const size_t y0 = k * rowsPerChunk, rows = std::min(rowsPerChunk, (size_t)H - y0);
-                HIP_TRY(hipMemcpyAsync(c->h_map[k & 1], c->stage_map + y0 * W, sizeof(float) * rows * W, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(hipEventRecord(c->map_ev[k & 1], c->stream));
-            }
-            if (k > 0) {
-                const size_t j = k - 1, y0 = j * rowsPerChunk, rows = std::min(rowsPerChunk, (size_t)H - y0);
-                HIP_TRY(hipEventSynchronize(c->map_ev[j & 1]));
-                const float* src = c->h_map[j & 1];
-                for (size_t y = 0; y < rows; ++y, src += W) {
-                    float* row = params->ssimMap + (ptrdiff_t)(y0 + y) * params->ssimStride;
-                    if (params->ssimStep == 1) memcpy(row, src, sizeof(float) * W);
-                    else for (uint32_t x = 0; x < W; ++x) row[(ptrdiff_t)x * params->ssimStep] = src[x];
-                }
-            }
-        }
-        HIP_TRY(hipStreamSynchronize(c->stream));
+    // A large pair whose map is wanted moves 2 B/px in and 4 B/px out over PCIe; the link is full duplex and the
+    // 0.1 ms kernel is nothing next to either.  The image is therefore cut into row bands: band k+1 is copied in
+    // while band k is computed (a row window of the same launch geometry; the cell-based reduction makes the sum
+    // bit-identical to the one-launch result) and band k-1's map rows travel back, written by a helper thread
+    // straight into the caller's buffer.
+    if (!staged && params->ssimMap && bandable(*params)) {
+        if ((rc = compute_banded(c, *params, dev, d, loA, loB))) return rc;
     } else {
+        if (!staged) {
+            HIP_TRY(hipMemcpyAsync(c->stage_a, params->imgA.topLeft + loA, (size_t)(hiA - loA + 1), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->stage_b, params->imgB.topLeft + loB, (size_t)(hiB - loB + 1), hipMemcpyHostToDevice, c->stream));
+        }
+        if ((rc = enqueue(c, W, H, 1, &d, d.map != NULL, c->h_sums))) return rc;      // sum lands in pinned host memory
+        if (params->ssimMap && W && H) {
+            if ((rc = map_rows_to_host(c, *params, 0, H, c->stream))) return rc;
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (ssim)
@@ -631,7 +877,7 @@ int stage_interleaved(rmgr_ssim_hip_Context* c, StagedPair& sp, const void* out1
         sp.guard = std::unique_lock<std::mutex>(c->lock);
     }
     sp.c = c;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     sp.pitch = ((size_t)width * channels + 3) & ~(size_t)3;      // dword-aligned rows for the packed luminance path
     const size_t bytes = sp.pitch * height + 4;
     if ((rc = grow_device(c->stage_a, c->stage_a_cap, bytes))) return rc;
@@ -654,7 +900,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* c,
                                                        rmgr_uint32_t width, rmgr_uint32_t height) RMGR_NOEXCEPT
 {
     if (!c || !dstY || !src || srcStep < 3) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(ssim_hip::launch_luminance(dstY, dstStride, src, srcStep, srcStride, width, height, c->stream));
     return 0;
 }
@@ -798,7 +1044,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_init(rmgr_ssim_hip_Context* c, const 
     if (!c || !id || rankCount < 1 || rank < 0 || rank >= rankCount || c->comm) return EINVAL;
     Rccl* r = rccl();
     if (!r) return ENOSYS;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     return map_nccl(r->CommInitRank(&c->comm, rankCount, u, rank));
@@ -810,7 +1056,7 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context*
     if (count == 0) return 0;
     Rccl* r = rccl();
     if (!r) return ENOSYS;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     return map_nccl(r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
 }
 
@@ -829,7 +1075,7 @@ extern "C" {
 rmgr_int32_t rmgr_ssim_hip_malloc(rmgr_ssim_hip_Context* c, void** p, size_t size) RMGR_NOEXCEPT
 {
     if (!c || !p) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(hipMalloc(p, size ? size : 1));
     return 0;
 }
@@ -837,7 +1083,7 @@ rmgr_int32_t rmgr_ssim_hip_malloc(rmgr_ssim_hip_Context* c, void** p, size_t siz
 rmgr_int32_t rmgr_ssim_hip_free(rmgr_ssim_hip_Context* c, void* p) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(hipFree(p));
     return 0;
 }
@@ -845,7 +1091,7 @@ rmgr_int32_t rmgr_ssim_hip_free(rmgr_ssim_hip_Context* c, void* p) RMGR_NOEXCEPT
 rmgr_int32_t rmgr_ssim_hip_memcpy_h2d(rmgr_ssim_hip_Context* c, void* dst, const void* src, size_t size) RMGR_NOEXCEPT
 {
     if (!c || (size && (!dst || !src))) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -854,7 +1100,7 @@ rmgr_int32_t rmgr_ssim_hip_memcpy_h2d(rmgr_ssim_hip_Context* c, void* dst, const
 rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* c, void* dst, const void* src, size_t size) RMGR_NOEXCEPT
 {
     if (!c || (size && (!dst || !src))) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     HIP_TRY(hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -870,13 +1116,22 @@ rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* c, rmgr_int32_t 
 rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* c, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
-    HIP_TRY(hipSetDevice(c->device));
+    USE_DEVICE(c);
     int rc = drain_profile(c);
     if (rc) return rc;
     if (launches) *launches = c->prof_launches;
     if (kernelMs) *kernelMs = c->prof_ms;
     c->prof_launches = 0;
     c->prof_ms = 0.0;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_synth_pair_device(rmgr_ssim_hip_Context* c, rmgr_uint8_t* imgA, ptrdiff_t strideA, rmgr_uint8_t* imgB, ptrdiff_t strideB,
+                                             rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint64_t seed) RMGR_NOEXCEPT
+{
+    if (!c || !imgA || !imgB) return EINVAL;
+    USE_DEVICE(c);
+    HIP_TRY(ssim_hip::launch_synth_pair(imgA, strideA, imgB, strideB, width, height, seed, c->stream));
     return 0;
 }
 

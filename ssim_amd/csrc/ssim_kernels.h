@@ -23,8 +23,10 @@ struct Geometry {
     uint32_t width, height, count;
     uint32_t strip_w;      // output columns per wavefront strip (64 or 128, by kernel)
     uint32_t strip_rows;   // output rows per wavefront strip
-    uint32_t strips_x, strips_y;
-    uint32_t partials_per_image() const { return strips_x * strips_y; }
+    uint32_t strips_x, strips_y;  // strips of THIS launch (its row window)
+    uint32_t y_begin, y_end;      // output rows [y_begin, y_end) this launch produces; y_begin is a multiple of 8
+    uint32_t cells_x, cells_y;    // the image's 64-column x 8-row reduction cells (ssim_kernels.hip, cell_flush*)
+    uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 
 // The two-column kernel addresses a strip's pixels as (64-bit uniform row base) + (32-bit lane offset) and keeps
@@ -58,21 +60,34 @@ inline int interleaved_group(const PairDesc* d, uint32_t count)
 }
 
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
-Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count);
+// y_begin / y_rows: the output rows the launch produces (default: the whole image).  A host that pipelines an image
+// in row bands launches consecutive windows -- each starting on a multiple of 8 rows -- into the same partials and
+// asks for the reduction with the last one; the sums are bit-identical to the single launch's.
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count,
+              uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu);
+
+// Doubles of device scratch launch() needs for `geo` (cell partials + the chunk sums of the two-stage reduction).
+size_t partials_size(const Geometry& geo);
 
 // Enqueues the SSIM kernel + the per-image reduction on `stream`.
 //   descs_dev   count descriptors in device memory, or NULL when count == 1 and `single` is used
-//   partials    device scratch, >= count * geo.partials_per_image() doubles
+//   partials    device scratch, >= partials_size(geo) doubles
+//   reduce      false: only the strip kernel of this row window runs (more windows follow); true: + the reduction
 //   sums        device, count doubles: per-image fp64 sum of the SSIM values
 //   group       > 1 when every run of `group` consecutive descriptors addresses the interleaved channels of one
 //               image pair (interleaved_group()): scheduling hint only, results do not depend on it
 // ev_begin/ev_end (optional) are recorded around the main kernel only.
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end);
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true);
 
 // BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.
 hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,
                             uint32_t width, uint32_t height, hipStream_t stream);
+
+// The synthetic test pattern of SURVEY.md 8(d) (integer-only, bit-reproducible; ssim_amd/synth.py and
+// oracle_synth_pair are its host twins), written straight into device memory: A and B planes, rows stride bytes apart.
+hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b_stride, uint32_t width, uint32_t height,
+                             uint64_t seed, hipStream_t stream);
 
 } // namespace ssim_hip
 

@@ -27,6 +27,7 @@
 // float division stays IEEE correctly rounded -- div_inrange_* is the compiler's own sequence minus
 // range handling that cannot trigger here -- and there is no -ffast-math anywhere).
 #include "ssim_kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <type_traits>
 
@@ -162,15 +163,34 @@ __device__ __forceinline__ d2 ring_fma(d2 h, double g, d2 c)
 // Separable blur (MODE_FAST fp32 / MODE_DOUBLE fp64): 1-D pass along the row on the folded
 // sums, then the vertical pass as the same ring scatter.  g[] = centre..edge taps of the true
 // 1-D Gaussian (g(x)g(y) equals the 2-D kernel of tests/ssim_naive.h to 7e-18).
-template <typename V, typename G>
+//
+// SMALL_FIRST: the row pass adds its terms from the outermost (smallest) tap inwards instead of centre first.
+// In fp32 the centre-first order -- the reference's own -- has a systematic rounding drift; through sigma^2 =
+// E[x^2] - mu^2 the mu planes carry almost all of it into the global value (einstein/jpg: -2.03e-6 against the
+// double oracle, the reference FMA path itself -1.55e-6).  MODE_FAST therefore sums its two mu streams small
+// taps first and keeps the E[.] streams centre first: on the 18 fixtures that is within 4.2e-7 of the exact value
+// (the reference's test tolerance is 2e-6) AND within 1.13e-6 of the FMA path (north_star's 1.5e-6); all five
+// streams small-first would be as accurate but 1.97e-6 from the FMA path on that image, all centre-first is the
+// 2.03e-6 above (tests/tools/fast_mode_model.py reproduces the numbers on the CPU).  Same instruction count.
+template <bool SMALL_FIRST = false, typename V, typename G>
 __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5, const G (&g)[6])
 {
-    V h = s0 * VT<V>::splat(g[0]);
-    h = fma_(s1, VT<V>::splat(g[1]), h);
-    h = fma_(s2, VT<V>::splat(g[2]), h);
-    h = fma_(s3, VT<V>::splat(g[3]), h);
-    h = fma_(s4, VT<V>::splat(g[4]), h);
-    h = fma_(s5, VT<V>::splat(g[5]), h);
+    V h;
+    if constexpr (SMALL_FIRST) {
+        h = s5 * VT<V>::splat(g[5]);
+        h = fma_(s4, VT<V>::splat(g[4]), h);
+        h = fma_(s3, VT<V>::splat(g[3]), h);
+        h = fma_(s2, VT<V>::splat(g[2]), h);
+        h = fma_(s1, VT<V>::splat(g[1]), h);
+        h = fma_(s0, VT<V>::splat(g[0]), h);
+    } else {
+        h = s0 * VT<V>::splat(g[0]);
+        h = fma_(s1, VT<V>::splat(g[1]), h);
+        h = fma_(s2, VT<V>::splat(g[2]), h);
+        h = fma_(s3, VT<V>::splat(g[3]), h);
+        h = fma_(s4, VT<V>::splat(g[4]), h);
+        h = fma_(s5, VT<V>::splat(g[5]), h);
+    }
     acc[0] = ring_fma(h, g[5], acc[1]);
     acc[1] = ring_fma(h, g[4], acc[2]);
     acc[2] = ring_fma(h, g[3], acc[3]);
@@ -259,9 +279,11 @@ struct KArgs {
     PairDesc        single;       // used when descs == nullptr
     const PairDesc* descs;
     uint32_t        width, height, strip_rows, strips_x, strips_y;
+    uint32_t        y_begin, y_end;   // output rows of this launch (a multiple-of-8 start; the whole image unless the host pipelines bands)
+    uint32_t        cells_x, cells_y; // the image's grid of 64-column x 8-row cells: the units of the fp64 reduction
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
-    double*         partials;     // [image][strip_y][strip_x]
+    double*         partials;     // [image][cell_y][cell_x]
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
     double          c1d, c2d;
@@ -332,19 +354,44 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     }
     st.W = args.width; st.H = args.height;
     st.x0 = (int64_t)st.sx * strip_w;
-    st.y0 = (int64_t)st.sy * args.strip_rows;
-    st.y_end = (st.y0 + args.strip_rows < st.H) ? st.y0 + args.strip_rows : st.H;
+    st.y0 = (int64_t)args.y_begin + (int64_t)st.sy * args.strip_rows;
+    st.y_end = (st.y0 + args.strip_rows < (int64_t)args.y_end) ? st.y0 + args.strip_rows : (int64_t)args.y_end;
     return st;
 }
 
-// Strip total: lanes in a fixed butterfly order -> one fp64 partial per strip.
-__device__ __forceinline__ void strip_finish(const KArgs& args, const Strip& st, double tot)
+// The fp64 reduction is organised in CELLS of 64 columns x 8 rows at absolute image positions, not in strips:
+// whatever the strip height, the kernel variant, the batch size or the row window of the launch, a cell's value is
+//   (1) per column, the cell's (up to 8) per-pixel values added in row order;
+//   (2) the two columns of each even/odd pair added;
+//   (3) a butterfly over the 32 pairs (partner distance 16, 8, 4, 2, 1; fp addition is commutative, so every
+//       lane of the butterfly holds the same bits);
+// and the per-image sum is ssim_reduce_kernel's fixed-order sum of the cells.  The sums are therefore bit-identical
+// however a batch is cut into launches, strips, bands or GPUs.  Strips start on multiples of 8 rows (plan()).
+// Cost: ~20 instructions per 8 rows per lane; 8 B of HBM per 512 pixels.
+__device__ __forceinline__ double butterfly32(double t)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        tot += __shfl_down(tot, off, 64);
+    for (int off = 16; off > 0; off >>= 1)
+        t += __shfl_xor(t, off, 64);
+    return t;
+}
+// two columns per lane: lanes 0-31 hold cell 2*sx, lanes 32-63 cell 2*sx+1; `pair` = column 2l + column 2l+1
+__device__ __forceinline__ void cell_flush2(const KArgs& args, const Strip& st, uint32_t cell_y, double pair)
+{
+    const double t = butterfly32(pair);
+    const uint32_t cx = 2u * st.sx + (threadIdx.x >> 5);
+    if ((threadIdx.x & 31u) == 0 && cx < args.cells_x)
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + cx] = t;
+}
+// one column per lane: the wave is one cell wide; `col` = the lane's column
+__device__ __forceinline__ void cell_flush1(const KArgs& args, const Strip& st, uint32_t cell_y, double col)
+{
+    double t = col + __shfl_xor(col, 1, 64);          // the even/odd pair
+#pragma unroll
+    for (int off = 32; off > 1; off >>= 1)            // the same butterfly, on pair index lane >> 1
+        t += __shfl_xor(t, off, 64);
     if (threadIdx.x == 0)
-        ((gptr_f64)args.partials)[((size_t)st.img * args.strips_y + st.sy) * args.strips_x + st.sx] = tot;
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + st.sx] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -544,7 +591,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if constexpr (EXACT) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
-            else                 blur_separable(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
+            else                 blur_separable<true>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
         }
         // (4) the (a*a,b*b) streams
         __builtin_amdgcn_sched_barrier(0);
@@ -613,15 +660,21 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
         row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    const int n_out = y_end - y0;
+    // Main rows, one reduction cell (8 output rows) at a time; only the image's last cell can be shorter.
+    uint32_t cell_y = (uint32_t)y0 >> 3;
 #pragma unroll 1
-    for (int i = n_out >> 1; i > 0; --i, r += 2) {
-        row(r, S0(), std::integral_constant<int, ROW_MAIN>());
-        row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+    for (int left = y_end - y0; left > 0; left -= 8, ++cell_y) {
+        const int rows = left < 8 ? left : 8;
+#pragma unroll 1
+        for (int i = rows >> 1; i > 0; --i, r += 2) {
+            row(r, S0(), std::integral_constant<int, ROW_MAIN>());
+            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+        }
+        if (rows & 1)
+            row(r, S0(), std::integral_constant<int, ROW_LAST>());
+        cell_flush2(args, st, cell_y, (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0));
+        colsum[0] = colsum[1] = 0.0;
     }
-    if (n_out & 1)
-        row(r, S0(), std::integral_constant<int, ROW_LAST>());
-    strip_finish(args, st, (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -737,9 +790,9 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     load_ab(ring[0]);
     fold_ab();
 
-    auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5) {
+    auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream) {
         if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
-        else if constexpr (MODE == MODE_FAST)                     blur_separable(acc, s0, s1, s2, s3, s4, s5, args.gf);
+        else if constexpr (MODE == MODE_FAST)                     blur_separable<decltype(mu_stream)::value>(acc, s0, s1, s2, s3, s4, s5, args.gf);
         else  // fp64 internals: the folded sums are exact integers in fp32; everything after is double
             blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
     };
@@ -756,13 +809,13 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
             wx[t] = s.x[base + t];
         }
         __builtin_amdgcn_sched_barrier(0);
-        blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4]);
+        blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4], std::true_type());
         __builtin_amdgcn_sched_barrier(0);
-        blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0]);
+        blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0], std::false_type());
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
-        blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0]);
+        blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type());
         __builtin_amdgcn_sched_barrier(0);
 
         if constexpr (phase != ROW_WARMUP) {         // ring entry 0 is the finished output row y = r - 5
@@ -799,25 +852,36 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
         row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    const int64_t n_out = y_end - y0;
+    uint32_t cell_y = (uint32_t)(y0 >> 3);
 #pragma unroll 1
-    for (int64_t i = n_out >> 1; i > 0; --i, r += 2) {
-        row(r, S0(), std::integral_constant<int, ROW_MAIN>());
-        row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+    for (int64_t left = y_end - y0; left > 0; left -= 8, ++cell_y) {
+        const int rows = left < 8 ? (int)left : 8;
+#pragma unroll 1
+        for (int i = rows >> 1; i > 0; --i, r += 2) {
+            row(r, S0(), std::integral_constant<int, ROW_MAIN>());
+            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+        }
+        if (rows & 1)
+            row(r, S0(), std::integral_constant<int, ROW_LAST>());
+        cell_flush1(args, st, cell_y, col_ok ? colsum : 0.0);
+        colsum = 0.0;
     }
-    if (n_out & 1)
-        row(r, S0(), std::integral_constant<int, ROW_LAST>());
-    strip_finish(args, st, col_ok ? colsum : 0.0);
 }
 
-// Per-image sum of the strip partials, fixed order (thread t takes partials t, t+256, ...; then
-// a fixed LDS tree), so the result is independent of launch timing, batch split and GPU count.
-__global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, double* __restrict__ sums)
+// Per-image sum of the cell partials in a fixed order (thread t takes partials t, t+256, ...; then a fixed LDS
+// tree), so the result depends on nothing but the image size.  Images with many cells (an 8192^2 pair has 131072)
+// are first cut into chunks of kReduceChunk cells, one block each (grid.y), then the chunk sums are summed the
+// same way: two short launches instead of one CU reading a megabyte.
+constexpr uint32_t kReduceChunk = 8192;
+
+__global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, uint32_t chunk, double* __restrict__ sums)
 {
     __shared__ double sh[256];
-    const double* p = partials + (size_t)blockIdx.x * per_image;
+    const uint32_t first = blockIdx.y * chunk;
+    const uint32_t n = per_image - first < chunk ? per_image - first : chunk;
+    const double* p = partials + (size_t)blockIdx.x * per_image + first;
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < per_image; i += 256)
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
         acc += p[i];
     sh[threadIdx.x] = acc;
     __syncthreads();
@@ -828,7 +892,7 @@ __global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restri
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        sums[blockIdx.x] = sh[0];
+        sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = sh[0];
 }
 
 template <int MODE>
@@ -907,18 +971,60 @@ hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src
     return hipGetLastError();
 }
 
+namespace {
+
+// r = splitmix64(seed ^ ((y << 32) | x)); g = ((3x + 5y) >> 2) & 255; A = (3g + (r & 255)) >> 2;
+// B = clamp(A + ((r >> 8) % 33) - 16, 0, 255).  HBM-bound (2 B written per pixel).
+__global__ __launch_bounds__(256) void synth_pair_kernel(uint8_t* __restrict__ a, int64_t a_stride, uint8_t* __restrict__ b, int64_t b_stride,
+                                                        uint32_t width, uint32_t height, uint64_t seed)
+{
+    const uint32_t y = blockIdx.y;
+    for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < width; x += gridDim.x * blockDim.x) {
+        uint64_t z = seed ^ (((uint64_t)y << 32) | x);
+        z += 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        const uint64_t r = z ^ (z >> 31);
+        const uint32_t g = ((3u * x + 5u * y) >> 2) & 255u;
+        const int32_t va = (int32_t)((3u * g + (uint32_t)(r & 255u)) >> 2);
+        const int32_t n = (int32_t)((r >> 8) % 33u) - 16;
+        const int32_t vb = va + n;
+        a[(int64_t)y * a_stride + x] = (uint8_t)va;
+        b[(int64_t)y * b_stride + x] = (uint8_t)(vb < 0 ? 0 : (vb > 255 ? 255 : vb));
+    }
+}
+
+} // namespace
+
+hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b_stride, uint32_t width, uint32_t height,
+                             uint64_t seed, hipStream_t stream)
+{
+    if (width == 0 || height == 0) return hipSuccess;
+    const dim3 grid(std::min<uint32_t>((width + 255) / 256, 64u), height), block(256);
+    hipLaunchKernelGGL(synth_pair_kernel, grid, block, 0, stream, a, a_stride, b, b_stride, width, height, seed);
+    return hipGetLastError();
+}
+
 static int columns_per_lane(int mode, int variant)
 {
     if (mode == MODE_DOUBLE) return 1;
     return variant == 1 ? 1 : 2;   // variant 1: one column per lane (lower VGPR use, more waves)
 }
 
-Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count)
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count,
+              uint32_t y_begin, uint32_t y_rows)
 {
     Geometry g;
     g.width = width; g.height = height; g.count = count;
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
+    g.cells_x = (width + 63) / 64;
+    g.cells_y = (height + 7) / 8;
+    // the rows this launch produces: [y_begin, y_begin + y_rows), clipped to the image; y_begin on a cell boundary
+    g.y_begin = (y_begin < height ? y_begin : height) & ~7u;
+    g.y_end = (y_rows >= height - g.y_begin) ? height : g.y_begin + y_rows;
+    const uint32_t rows_total = g.y_end - g.y_begin;
+    auto round8 = [](uint32_t v) { return (v + 7u) & ~7u; };
     if (strip_rows <= 0) {
         // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per SIMD on
         // every CU.  512-row strips when that leaves >= 32 strips per CU (measured +1.5 % on 32 x 4096^2 over 256,
@@ -929,10 +1035,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         //   more                         n u / S + 0.3 u   (throughput-bound, plus a tail)
         // taller winning ties.  A launch that cannot fill the GPU is thereby cut into short strips: 256^2 runs as
         // 64 strips of 8 rows in half the time of 16 strips of 32.  Strips are then evened out (1080 rows ->
-        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one.
+        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one, in whole reduction cells (8 rows).
         const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
-        auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((height + rows - 1) / rows) * count; };
-        auto evened = [&](uint32_t rows) { const uint32_t ny = height ? (height + rows - 1) / rows : 1; return height ? (height + ny - 1) / ny : rows; };
+        auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((rows_total + rows - 1) / rows) * count; };
+        auto evened = [&](uint32_t rows) { const uint32_t ny = rows_total ? (rows_total + rows - 1) / rows : 1; return rows_total ? round8((rows_total + ny - 1) / ny) : rows; };
         uint32_t rows = 512;
         if (strips(rows) < cus * 32) {
             uint64_t best = ~(uint64_t)0;
@@ -942,17 +1048,39 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
                 if (cost < best) { best = cost; rows = cand; }
             }
         }
-        const uint32_t ny = height ? (height + rows - 1) / rows : 1;
-        strip_rows = (int)(height ? (height + ny - 1) / ny : rows);
+        strip_rows = (int)evened(rows);
     }
     if (strip_rows < 1) strip_rows = 1;
-    g.strip_rows = (uint32_t)strip_rows;
-    g.strips_y = height ? (height + g.strip_rows - 1) / g.strip_rows : 0;
+    g.strip_rows = round8((uint32_t)strip_rows);      // strips start on cell boundaries
+    g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
     return g;
 }
 
+size_t partials_size(const Geometry& geo)
+{
+    const size_t per = geo.partials_per_image();
+    const size_t chunks = per > kReduceChunk ? (per + kReduceChunk - 1) / kReduceChunk : 0;
+    return (size_t)geo.count * (per + chunks) + 1;
+}
+
+hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hipStream_t stream)
+{
+    if (geo.count == 0) return hipSuccess;
+    const uint32_t per = geo.partials_per_image();
+    if (per == 0) return hipMemsetAsync(sums, 0, sizeof(double) * geo.count, stream);
+    if (per > kReduceChunk) {
+        const uint32_t chunks = (per + kReduceChunk - 1) / kReduceChunk;
+        double* chunk_sums = partials + (size_t)geo.count * per;
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(256), 0, stream, partials, per, kReduceChunk, chunk_sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(256), 0, stream, chunk_sums, chunks, chunks, sums);
+    } else {
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(256), 0, stream, partials, per, per, sums);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end)
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce)
 {
     if (geo.count == 0) return hipSuccess;
     KArgs ka;
@@ -960,6 +1088,8 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.descs = descs_dev;
     ka.width = geo.width; ka.height = geo.height;
     ka.strip_rows = geo.strip_rows; ka.strips_x = geo.strips_x; ka.strips_y = geo.strips_y;
+    ka.y_begin = geo.y_begin; ka.y_end = geo.y_end;
+    ka.cells_x = geo.cells_x; ka.cells_y = geo.cells_y;
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;
@@ -981,10 +1111,8 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
         }
     }
     bool map = single.map != nullptr;   // for batches the ABI guarantees all-or-none and mirrors it into `single`
-    if (geo.strips_x == 0 || geo.strips_y == 0) {
-        hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * geo.count, stream);
-        return e;
-    }
+    if (geo.strips_x == 0 || geo.strips_y == 0)
+        return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
     hipError_t err;
     // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel).
@@ -999,8 +1127,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     }
     if (err != hipSuccess) return err;
     if (ev_end) { hipError_t e = hipEventRecord(ev_end, stream); if (e != hipSuccess) return e; }
-    hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count), dim3(256), 0, stream, partials, geo.partials_per_image(), sums);
-    return hipGetLastError();
+    return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
 }
 
 } // namespace ssim_hip

@@ -1,0 +1,227 @@
+"""GPU: round-2 additions to the C ABI.
+
+* BASELINE.json configs[3] at full count (1024 x 1080p) with the 8-GPU sharding emulated on one device and the
+  native RCCL exchange (tests/tools/config4_selftest.py, own process);
+* the cell-based fp64 reduction: per-image sums bit-identical for any strip height, kernel variant, batch split;
+* the descriptor-table ring: different batches enqueued back to back without draining the stream;
+* the banded (pipelined) host-pointer call: value and map bit-identical to the device path, for every map layout;
+* MODE_FAST against the reference's OWN test tolerances (naive double oracle: 2e-6 global, 1e-3 per pixel,
+  tests/rmgr-ssim-tests.cpp:98-104) in addition to north_star's FMA-relative ones (tests/test_gpu_modes.py);
+* the synthetic generator kernel against its host twins.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ssim_amd
+from ssim_amd import synth
+from conftest import GOLDEN, ROOT, f32_hex, image_entries, load_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, np.float64).view(np.uint64)
+
+
+def test_config4_1024_pairs_1080p_sharded_equals_single_batch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "config4_selftest.py")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout.split(), (r.stdout[-800:], r.stderr[-1500:])
+    print(r.stdout.strip().splitlines()[0])
+
+
+def test_synth_generator_matches_host_twins(gpu_ctx, oracle):
+    for (w, h, seed) in ((301, 77, 0x5EED), (1920, 9, 0x5EEE), (64, 64, 0x5EED + 1023), (1, 1, 7)):
+        da, db = gpu_ctx.alloc(w * h), gpu_ctx.alloc(w * h)
+        try:
+            gpu_ctx.synth_pair(da.ptr, w, db.ptr, w, w, h, seed)
+            gpu_ctx.synchronize()
+            a, b = da.download(np.uint8, (h, w)), db.download(np.uint8, (h, w))
+        finally:
+            da.free()
+            db.free()
+        oa, ob = oracle.synth_pair(w, h, seed)
+        na, nb = synth.pair_numpy(w, h, seed)
+        assert np.array_equal(a, oa) and np.array_equal(b, ob), (w, h, seed)
+        assert np.array_equal(a, na) and np.array_equal(b, nb), (w, h, seed)
+    da, db = gpu_ctx.alloc(16), gpu_ctx.alloc(16)
+    gpu_ctx.synth_pair(da.ptr, 4, db.ptr, 4, 4, 1, 0x5EED)
+    gpu_ctx.synchronize()
+    assert list(da.download(np.uint8, (4,))) == [45, 59, 51, 6] and list(db.download(np.uint8, (4,))) == [51, 58, 48, 5]
+    da.free()
+    db.free()
+
+
+def hostile_pairs(rng, w, h, n):
+    """Pairs whose per-pixel SSIM values span [-1, 1] with many tiny magnitudes: fp64 partial sums of such values
+    are NOT exact, so any change of the summation grouping shows up in the last bits of the per-image sum."""
+    out = []
+    for i in range(n):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        if i % 3 == 0:
+            b = 255 - a                                  # anti-correlated: values near -1 .. 0
+        elif i % 3 == 1:
+            b = rng.integers(0, 256, (h, w), dtype=np.uint8)   # uncorrelated: values around 0
+        else:
+            b = np.clip(a.astype(np.int32) + rng.integers(-90, 91, (h, w)), 0, 255).astype(np.uint8)
+        out.append((a, b))
+    return out
+
+
+def batch_sums(ctx, pairs, keep, split=None):
+    """fp64 per-image sums of host pairs through enqueue_batch; `split`: list of (first, last) sub-batches."""
+    n = len(pairs)
+    h, w = pairs[0][0].shape
+    params = (ssim_amd.Params * n)()
+    for i, (a, b) in enumerate(pairs):
+        da, db = ctx.upload(a), ctx.upload(b)
+        keep += [da, db]
+        params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w)
+    sums = ctx.alloc(8 * n).upload(np.zeros(n))
+    keep.append(sums)
+    for first, last in (split or [(0, n)]):
+        sub = (ssim_amd.Params * (last - first))(*[params[i] for i in range(first, last)])
+        ctx.enqueue_batch(sub, last - first, sums.ptr + 8 * first)
+    ctx.synchronize()
+    return sums.download(np.float64, (n,))
+
+
+@pytest.mark.parametrize("mode", [ssim_amd.MODE_EXACT, ssim_amd.MODE_FAST, ssim_amd.MODE_DOUBLE])
+def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode):
+    rng = np.random.default_rng(20260101 + mode)
+    pairs = hostile_pairs(rng, 333, 411, 6)             # 411 rows: a last reduction cell of 3 rows; 333 columns: ragged strips
+    keep = []
+    gpu_ctx.set_mode(mode)
+    try:
+        gpu_ctx.set_tuning(0, 0)
+        ref = batch_sums(gpu_ctx, pairs, keep)
+        assert np.all(np.isfinite(ref))
+        for strip_rows, variant, split in ((8, 0, None), (24, 0, None), (64, 1, None), (216, 0, None), (512, 1, None),
+                                           (0, 1, None), (0, 0, [(0, 1), (1, 4), (4, 6)]), (40, 0, [(0, 5), (5, 6)])):
+            gpu_ctx.set_tuning(strip_rows, variant)
+            got = batch_sums(gpu_ctx, pairs, keep, split)
+            assert np.array_equal(bits64(got), bits64(ref)), (mode, strip_rows, variant, split, got - ref)
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+        for d in keep:
+            d.free()
+
+
+def test_different_batches_back_to_back(gpu_ctx, oracle):
+    """Six different batches (more than the descriptor ring holds) enqueued without any synchronisation in between,
+    then two of them alternating: every result must be the one of its own batch."""
+    rng = np.random.default_rng(5)
+    w, h = 200, 96
+    keep, batches, want = [], [], []
+    try:
+        for k in range(6):
+            n = 2 + k % 3
+            params = (ssim_amd.Params * n)()
+            sums = []
+            for i in range(n):
+                a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+                b = np.clip(a.astype(np.int32) + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)
+                da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+                keep += [da, db]
+                params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w)
+                sums.append(oracle.ssim_f32(a, b)[0])
+            out = gpu_ctx.alloc(8 * n)
+            keep.append(out)
+            batches.append((params, n, out))
+            want.append(np.array(sums, np.float32))
+        for rounds in range(3):
+            for params, n, out in batches:
+                gpu_ctx.enqueue_batch(params, n, out.ptr)
+        for _ in range(10):
+            for k in (4, 1):
+                gpu_ctx.enqueue_batch(batches[k][0], batches[k][1], batches[k][2].ptr)
+        gpu_ctx.synchronize()
+        for (params, n, out), w_ in zip(batches, want):
+            got = ssim_amd.finalize(out.download(np.float64, (n,)), w, h)
+            assert np.array_equal(got.view(np.uint32), w_.view(np.uint32))
+    finally:
+        for d in keep:
+            d.free()
+
+
+def host_call(a, b, a_step, a_stride, a_ptr, b_step, b_stride, b_ptr, w, h, m_ptr=None, m_step=1, m_stride=None, want_global=True):
+    lib = ssim_amd.load_library()
+    p = ssim_amd.make_params(w, h, a_ptr, a_step, a_stride, b_ptr, b_step, b_stride, m_ptr, m_step, m_stride)
+    out = ctypes.c_float(-2.0)
+    rc = lib.rmgr_ssim_compute_ssim(ctypes.byref(out) if want_global else None, ctypes.byref(p), None)
+    assert rc == 0, rc
+    return np.float32(out.value)
+
+
+@pytest.mark.parametrize("w,h", [(4096, 4096), (3000, 1237), (1031, 260)])
+def test_banded_host_call_equals_device_path(gpu_ctx, oracle, w, h):
+    """The host-pointer call with a map on images large enough for the banded pipeline: global value and every map
+    pixel bit-identical to the one-launch device path -- dense map, padded rows, a column-interleaved map (the
+    CPU-scatter path), bottom-up images, and map-only calls.  4096^2 is also checked against the known answer."""
+    a, b = oracle.synth_pair(w, h, 0x5EED)
+    gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    v_dev, m_dev = gpu_ctx.ssim_planes(a, b, want_map=True)
+    if (w, h) == (4096, 4096):
+        assert f32_hex(v_dev) == "0x3f64b7be"
+    # dense
+    m = np.full((h, w), -7.0, np.float32)
+    v = host_call(a, b, 1, w, a.ctypes.data, 1, w, b.ctypes.data, w, h, m.ctypes.data, 1, w)
+    assert f32_hex(v) == f32_hex(v_dev)
+    assert np.array_equal(m.view(np.uint32), m_dev.view(np.uint32))
+    # padded map rows + map-only call (ssim == NULL)
+    pad = np.full((h, w + 13), -7.0, np.float32)
+    host_call(a, b, 1, w, a.ctypes.data, 1, w, b.ctypes.data, w, h, pad.ctypes.data, 1, w + 13, want_global=False)
+    assert np.array_equal(pad[:, :w].view(np.uint32), m_dev.view(np.uint32)) and np.all(pad[:, w:] == -7.0)
+    # map elements two floats apart (scatter path), images bottom-up (negative stride)
+    inter = np.full((h, 2 * w), -7.0, np.float32)
+    af, bf = np.ascontiguousarray(a[::-1]), np.ascontiguousarray(b[::-1])
+    v2 = host_call(af, bf, 1, -w, af.ctypes.data + (h - 1) * w, 1, -w, bf.ctypes.data + (h - 1) * w, w, h, inter.ctypes.data, 2, 2 * w)
+    assert f32_hex(v2) == f32_hex(v_dev)
+    assert np.array_equal(inter[:, 0::2].view(np.uint32), m_dev.view(np.uint32)) and np.all(inter[:, 1::2] == -7.0)
+    # every band count the pipeline can be asked for gives the same bits (own processes: the default context reads the env once)
+    if (w, h) == (3000, 1237):
+        code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle, ssim_amd; a,b=oracle.synth_pair(%d,%d,0x5EED); "
+                "v,m=ssim_amd.compute_ssim(a,b,want_map=True); import hashlib; print('%%08x'%%int(np.float32(v).view(np.uint32)), hashlib.sha256(m.tobytes()).hexdigest())" % (ROOT, w, h))
+        import hashlib
+        want = "%08x %s" % (int(np.float32(v_dev).view(np.uint32)), hashlib.sha256(m_dev.tobytes()).hexdigest())
+        for bands in ("1", "2", "3", "7", "16"):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, RMGR_SSIM_HIP_BANDS=bands))
+            assert r.returncode == 0, r.stderr[-800:]
+            assert r.stdout.strip().splitlines()[-1] == want, (bands, r.stdout)
+
+
+def test_fast_mode_meets_the_reference_test_tolerances(gpu_ctx, manifest):
+    """tests/rmgr-ssim-tests.cpp:98-104, :310-326 asks of any implementation: global within 2e-6 and every pixel within
+    1e-3 of the naive double oracle.  MODE_FAST must meet that (it failed by 1 % in round 1: 2.02e-6 on einstein/jpg)
+    AND north_star's FMA-relative 1.5e-6 / 6.3e-4; the margins are asserted, not printed."""
+    gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+    worst_g = worst_p = worst_gf = 0.0
+    try:
+        for variant in (0, 1):
+            gpu_ctx.set_tuning(0, variant)
+            for name in image_entries(manifest):
+                ent = manifest[name]
+                a, b = load_pair(ent)
+                v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+                dg = abs(float(v) - float(ent["naive_f64"]["ssim"]))
+                worst_g = max(worst_g, dg)
+                worst_gf = max(worst_gf, abs(float(v) - float(ent["fma"]["ssim"])))
+                assert dg < 2e-6, (name, dg)
+                if "map" in ent["naive_f64"]:
+                    nmap = np.load(os.path.join(GOLDEN, ent["naive_f64"]["map"]))
+                    dp = float(np.abs(m.astype(np.float64) - nmap).max())
+                    worst_p = max(worst_p, dp)
+                    assert dp < 1e-3, (name, dp)
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    # the CPU model of the kernel's arithmetic (tests/tools/fast_mode_model.py) predicts 4.2e-7 / 1.13e-6 / 1.9e-4
+    assert worst_g < 6e-7, worst_g
+    assert worst_gf < 1.3e-6, worst_gf
+    assert worst_p < 3e-4, worst_p
