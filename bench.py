@@ -267,6 +267,10 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
             mm = float(batch.imgs[0][2].double().mean().item())
             if abs(mm - float(res[0])) > 1e-6:
                 raise SystemExit("%s: map mean %.9f disagrees with the global SSIM %.9f" % (name, mm, float(res[0])))
+        t_settle = time.perf_counter()          # the clock has dropped while the host checked the results: settle, untimed
+        while time.perf_counter() - t_settle < 0.15:
+            ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
+            ctx.synchronize()
         for _ in range(2):
             ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
         ctx.synchronize()

@@ -365,10 +365,13 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
 {
     (void)dev;
     const uint32_t W = p.width, H = p.height;
-    int bands = 4;
+    // Band size: ~2 Mpixel (8 MB of map) per band, at most kMaxBands -- measured on MI355X / PCIe Gen5 (profiles/
+    // r02_host_probe.txt): 4096^2 10.6 Gpix/s at 6-8 bands (8.2 unpipelined), 8192^2 12.0 at 16 (8.7), 2048^2 8.1 at 2 (7.0).
+    int bands = (int)std::min<uint64_t>(((uint64_t)W * H + (1u << 21) - 1) >> 21, rmgr_ssim_hip_Context_::kMaxBands);
     if (const char* e = getenv("RMGR_SSIM_HIP_BANDS")) bands = atoi(e);
     bands = std::max(1, std::min<int>(bands, rmgr_ssim_hip_Context_::kMaxBands));
-    uint32_t band_rows = ((H + bands - 1) / bands + 7u) & ~7u;
+    const uint32_t cell = ssim_hip::cell_rows_for(H);         // windows start on reduction-cell boundaries
+    uint32_t band_rows = ((H + bands - 1) / bands + cell - 1) & ~(cell - 1);
     if (band_rows < 64) band_rows = 64;
     const int n = (int)((H + band_rows - 1) / band_rows);
     if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -378,11 +381,11 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
         if (!c->band_done[k]) HIP_TRY(hipEventCreateWithFlags(&c->band_done[k], hipEventDisableTiming));
     }
     // input chunk k = rows [in[k], in[k+1]); once it has landed, output rows [out[k], out[k+1]) can be computed:
-    // everything up to 8 rows (>= the 5 halo rows, and a whole reduction cell) short of the rows present.
+    // everything up to one reduction cell (>= the 5 halo rows) short of the rows present.
     uint32_t in[rmgr_ssim_hip_Context_::kMaxBands + 1], out[rmgr_ssim_hip_Context_::kMaxBands + 1];
     for (int k = 0; k <= n; ++k) {
         in[k] = std::min<uint64_t>((uint64_t)k * band_rows, H);
-        out[k] = (k == 0) ? 0 : (k == n ? H : in[k] - 8);
+        out[k] = (k == 0) ? 0 : (k == n ? H : in[k] - cell);
     }
 
     // The helper thread returns band k's map rows while the caller's thread feeds bands k+1, k+2, ...

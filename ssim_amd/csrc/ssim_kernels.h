@@ -24,8 +24,9 @@ struct Geometry {
     uint32_t strip_w;      // output columns per wavefront strip (64 or 128, by kernel)
     uint32_t strip_rows;   // output rows per wavefront strip
     uint32_t strips_x, strips_y;  // strips of THIS launch (its row window)
-    uint32_t y_begin, y_end;      // output rows [y_begin, y_end) this launch produces; y_begin is a multiple of 8
-    uint32_t cells_x, cells_y;    // the image's 64-column x 8-row reduction cells (ssim_kernels.hip, cell_flush*)
+    uint32_t y_begin, y_end;      // output rows [y_begin, y_end) this launch produces; y_begin is a multiple of cell_rows
+    uint32_t cell_rows;           // rows per reduction cell: cell_rows_for(height)
+    uint32_t cells_x, cells_y;    // the image's 64-column x cell_rows-row reduction cells (ssim_kernels.hip, cell_flush*)
     uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 
@@ -60,8 +61,16 @@ inline int interleaved_group(const PairDesc* d, uint32_t count)
 }
 
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
+// Rows per cell of the fp64 reduction: a function of the image height ONLY, so that every launch that touches an
+// image of this size -- any strip height, batch, band or GPU -- builds the same cells.  Images below 2048 rows keep
+// 8-row cells: a lone small image is cut into 8-row strips to fill the GPU, and 1080 rows split into five even
+// 216-row strips only in 8-row units (16-row cells -> 4 x 224 + 184 measured 2 % slower than the cells save).
+// Taller images amortise the per-cell cost over 32 rows (MODE_EXACT, 32 x 4096^2: -0.8 % vs no cells at all, 8-row
+// cells -1.5...-3 %; profiles/r02_cells_ab.txt).
+inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8u; }
+
 // y_begin / y_rows: the output rows the launch produces (default: the whole image).  A host that pipelines an image
-// in row bands launches consecutive windows -- each starting on a multiple of 8 rows -- into the same partials and
+// in row bands launches consecutive windows -- each starting on a cell boundary -- into the same partials and
 // asks for the reduction with the last one; the sums are bit-identical to the single launch's.
 Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count,
               uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu);

@@ -280,7 +280,8 @@ struct KArgs {
     const PairDesc* descs;
     uint32_t        width, height, strip_rows, strips_x, strips_y;
     uint32_t        y_begin, y_end;   // output rows of this launch (a multiple-of-8 start; the whole image unless the host pipelines bands)
-    uint32_t        cells_x, cells_y; // the image's grid of 64-column x 8-row cells: the units of the fp64 reduction
+    uint32_t        cells_x, cells_y; // the image's grid of 64-column x cell_rows-row cells: the units of the fp64 reduction
+    uint32_t        cell_shift;       // log2(cell_rows): 3 or 5 by image height (cell_rows_for())
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
@@ -359,39 +360,60 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     return st;
 }
 
-// The fp64 reduction is organised in CELLS of 64 columns x 8 rows at absolute image positions, not in strips:
-// whatever the strip height, the kernel variant, the batch size or the row window of the launch, a cell's value is
-//   (1) per column, the cell's (up to 8) per-pixel values added in row order;
+// The fp64 reduction is organised in CELLS of 64 columns x cell_rows rows at absolute image positions, not in
+// strips (cell_rows is 8 or 32, a function of the image height alone: cell_rows_for()).  Whatever the strip
+// height, the kernel variant, the batch size or the row window of the launch, a cell's value is
+//   (1) per column, the cell's (up to cell_rows) per-pixel values added in row order;
 //   (2) the two columns of each even/odd pair added;
-//   (3) a butterfly over the 32 pairs (partner distance 16, 8, 4, 2, 1; fp addition is commutative, so every
+//   (3) a butterfly over the 32 pairs (partner distance 1, 2, 4, 8, 16; fp addition is commutative, so every
 //       lane of the butterfly holds the same bits);
 // and the per-image sum is ssim_reduce_kernel's fixed-order sum of the cells.  The sums are therefore bit-identical
-// however a batch is cut into launches, strips, bands or GPUs.  Strips start on multiples of 8 rows (plan()).
-// Cost: ~20 instructions per 8 rows per lane; 8 B of HBM per 512 pixels.
-__device__ __forceinline__ double butterfly32(double t)
+// however a batch is cut into launches, strips, bands or GPUs.  Strips start on cell boundaries (plan()).
+// Cost: ~80 issue slots per cell and wave (measured: 2.5 % of MODE_EXACT with 8-row cells, hence the taller
+// cells for taller images: 0.6 % at 32 rows); 8 B of HBM per cell.
+// The tree runs on DPP lane permutations (plain VALU moves: no LDS round trip to wait for), each level adding the
+// partner's value so that ALL lanes of the growing group hold the same bits: pairs 1 apart and 2 apart with
+// quad_perm, then -- quads being uniform -- 4 apart is row_half_mirror (lane i <-> 7-i of each 8) and 8 apart is
+// row_mirror (i <-> 15-i of each 16); the 16-lane rows are then combined through v_readlane.
+#define SSIM_DPP_ADD(t, CTRL) do {                                                                            \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(t), (CTRL), 0xF, 0xF, false);           \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(t), (CTRL), 0xF, 0xF, false);           \
+        (t) += __hiloint2double(hi_, lo_);                                                                    \
+    } while (0)
+__device__ __forceinline__ double lane_value(double t, int lane)
 {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1)
-        t += __shfl_xor(t, off, 64);
-    return t;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), lane), __builtin_amdgcn_readlane(__double2loint(t), lane));
 }
+enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140 };
+
 // two columns per lane: lanes 0-31 hold cell 2*sx, lanes 32-63 cell 2*sx+1; `pair` = column 2l + column 2l+1
 __device__ __forceinline__ void cell_flush2(const KArgs& args, const Strip& st, uint32_t cell_y, double pair)
 {
-    const double t = butterfly32(pair);
-    const uint32_t cx = 2u * st.sx + (threadIdx.x >> 5);
-    if ((threadIdx.x & 31u) == 0 && cx < args.cells_x)
-        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + cx] = t;
+    double t = pair;
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // pairs 1 apart
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // 2 apart
+    SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 4 apart
+    SSIM_DPP_ADD(t, DPP_ROW_MIRROR);           // 8 apart: every lane of a 16-lane row holds the row's 16 pairs
+    const double c0 = lane_value(t, 0) + lane_value(t, 16);      // 16 apart
+    const double c1 = lane_value(t, 32) + lane_value(t, 48);
+    if (threadIdx.x == 0) {
+        const uint32_t cx = 2u * st.sx;
+        const gptr_f64 p = (gptr_f64)args.partials + ((size_t)st.img * args.cells_y + cell_y) * args.cells_x + cx;
+        p[0] = c0;
+        if (cx + 1 < args.cells_x) p[1] = c1;
+    }
 }
 // one column per lane: the wave is one cell wide; `col` = the lane's column
 __device__ __forceinline__ void cell_flush1(const KArgs& args, const Strip& st, uint32_t cell_y, double col)
 {
-    double t = col + __shfl_xor(col, 1, 64);          // the even/odd pair
-#pragma unroll
-    for (int off = 32; off > 1; off >>= 1)            // the same butterfly, on pair index lane >> 1
-        t += __shfl_xor(t, off, 64);
+    double t = col;
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // the even/odd column pair
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // pairs 1 apart
+    SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 2 apart
+    SSIM_DPP_ADD(t, DPP_ROW_MIRROR);           // 4 apart: a row holds its 8 pairs
+    const double c = (lane_value(t, 0) + lane_value(t, 16)) + (lane_value(t, 32) + lane_value(t, 48));   // 8 apart, 16 apart
     if (threadIdx.x == 0)
-        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + st.sx] = t;
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + st.sx] = c;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -660,11 +682,12 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
         row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    // Main rows, one reduction cell (8 output rows) at a time; only the image's last cell can be shorter.
-    uint32_t cell_y = (uint32_t)y0 >> 3;
+    // Main rows, one reduction cell at a time; only the image's last cell can be shorter.
+    const int cell_rows = 1 << args.cell_shift;
+    uint32_t cell_y = (uint32_t)y0 >> args.cell_shift;
 #pragma unroll 1
-    for (int left = y_end - y0; left > 0; left -= 8, ++cell_y) {
-        const int rows = left < 8 ? left : 8;
+    for (int left = y_end - y0; left > 0; left -= cell_rows, ++cell_y) {
+        const int rows = left < cell_rows ? left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
             row(r, S0(), std::integral_constant<int, ROW_MAIN>());
@@ -852,10 +875,11 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
         row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
-    uint32_t cell_y = (uint32_t)(y0 >> 3);
+    const int cell_rows = 1 << args.cell_shift;
+    uint32_t cell_y = (uint32_t)(y0 >> args.cell_shift);
 #pragma unroll 1
-    for (int64_t left = y_end - y0; left > 0; left -= 8, ++cell_y) {
-        const int rows = left < 8 ? (int)left : 8;
+    for (int64_t left = y_end - y0; left > 0; left -= cell_rows, ++cell_y) {
+        const int rows = left < cell_rows ? (int)left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
             row(r, S0(), std::integral_constant<int, ROW_MAIN>());
@@ -1018,13 +1042,15 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.width = width; g.height = height; g.count = count;
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
+    g.cell_rows = cell_rows_for(height);
+    const uint32_t cr = g.cell_rows;
     g.cells_x = (width + 63) / 64;
-    g.cells_y = (height + 7) / 8;
+    g.cells_y = (height + cr - 1) / cr;
     // the rows this launch produces: [y_begin, y_begin + y_rows), clipped to the image; y_begin on a cell boundary
-    g.y_begin = (y_begin < height ? y_begin : height) & ~7u;
+    g.y_begin = (y_begin < height ? y_begin : height) & ~(cr - 1);
     g.y_end = (y_rows >= height - g.y_begin) ? height : g.y_begin + y_rows;
     const uint32_t rows_total = g.y_end - g.y_begin;
-    auto round8 = [](uint32_t v) { return (v + 7u) & ~7u; };
+    auto round8 = [cr](uint32_t v) { return (v + cr - 1) & ~(cr - 1); };      // up to whole cells
     if (strip_rows <= 0) {
         // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per SIMD on
         // every CU.  512-row strips when that leaves >= 32 strips per CU (measured +1.5 % on 32 x 4096^2 over 256,
@@ -1035,14 +1061,14 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         //   more                         n u / S + 0.3 u   (throughput-bound, plus a tail)
         // taller winning ties.  A launch that cannot fill the GPU is thereby cut into short strips: 256^2 runs as
         // 64 strips of 8 rows in half the time of 16 strips of 32.  Strips are then evened out (1080 rows ->
-        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one, in whole reduction cells (8 rows).
+        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one, in whole reduction cells.
         const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
         auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((rows_total + rows - 1) / rows) * count; };
         auto evened = [&](uint32_t rows) { const uint32_t ny = rows_total ? (rows_total + rows - 1) / rows : 1; return rows_total ? round8((rows_total + ny - 1) / ny) : rows; };
         uint32_t rows = 512;
         if (strips(rows) < cus * 32) {
             uint64_t best = ~(uint64_t)0;
-            for (uint32_t cand = 256; cand >= 8; cand >>= 1) {
+            for (uint32_t cand = 256; cand >= cr; cand >>= 1) {
                 const uint64_t n = strips(cand), u = evened(cand) + 10;
                 const uint64_t cost = n <= simds ? 137 * u : n <= 2 * simds ? 200 * u : 100 * n * u / simds + 30 * u;
                 if (cost < best) { best = cost; rows = cand; }
@@ -1090,6 +1116,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.strip_rows = geo.strip_rows; ka.strips_x = geo.strips_x; ka.strips_y = geo.strips_y;
     ka.y_begin = geo.y_begin; ka.y_end = geo.y_end;
     ka.cells_x = geo.cells_x; ka.cells_y = geo.cells_y;
+    ka.cell_shift = geo.cell_rows == 32 ? 5 : geo.cell_rows == 16 ? 4 : 3;
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;

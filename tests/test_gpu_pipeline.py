@@ -91,10 +91,11 @@ def batch_sums(ctx, pairs, keep, split=None):
     return sums.download(np.float64, (n,))
 
 
+@pytest.mark.parametrize("size", [(333, 411), (130, 1100), (200, 2100)])      # 8-row and 32-row reduction cells, each with a short last cell
 @pytest.mark.parametrize("mode", [ssim_amd.MODE_EXACT, ssim_amd.MODE_FAST, ssim_amd.MODE_DOUBLE])
-def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode):
+def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size):
     rng = np.random.default_rng(20260101 + mode)
-    pairs = hostile_pairs(rng, 333, 411, 6)             # 411 rows: a last reduction cell of 3 rows; 333 columns: ragged strips
+    pairs = hostile_pairs(rng, size[0], size[1], 6)     # ragged strips in both directions
     keep = []
     gpu_ctx.set_mode(mode)
     try:
