@@ -16,13 +16,24 @@ HIPFLAGS := $(if $(DOUBLE),-DRMGR_SSIM_USE_DOUBLE=1) --offload-arch=$(ARCH) -O3 
 
 all: lib oracle
 
-lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim.a $(BIN)/rmgr-ssim
+lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(BIN)/rmgr-ssim
 
 # Static flavour under the reference's archive name (CMakeLists.txt:205): the same three objects.  A program
 # that links it also needs the HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
 $(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
 	@mkdir -p $(OUT)
 	rm -f $@ && ar rcs $@ $^
+
+# The reference's second archive (CMakeLists.txt:229: rmgr-ssim-openmp = src/ssim-openmp.c).  Here the OpenMP entry
+# point is a forwarder that lives in ssim_dropin.o already; the archive exists so that a link line written for the
+# reference (-lrmgr-ssim-openmp -lrmgr-ssim) resolves unchanged.  It carries one marker object.
+$(OUT)/librmgr-ssim-openmp.a: $(OBJ)/ssim_openmp_marker.o
+	@mkdir -p $(OUT)
+	rm -f $@ && ar rcs $@ $^
+
+$(OBJ)/ssim_openmp_marker.o: $(SRC)/ssim_openmp_marker.c
+	@mkdir -p $(OBJ)
+	$(CC) -std=c89 -pedantic -O2 -fPIC -Wall -Iinclude -c $< -o $@
 
 $(OBJ)/ssim_kernels.o: $(SRC)/ssim_kernels.hip $(SRC)/ssim_kernels.h
 	@mkdir -p $(OBJ)
@@ -33,7 +44,7 @@ $(OBJ)/ssim_hip_abi.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h include/rmg
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 # The drop-in layer is plain C++98 compiled by the host compiler: no HIP on this side.
-$(OBJ)/ssim_dropin.o: $(SRC)/ssim_dropin.cpp include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-hip.h include/rmgr/ssim-version.h
+$(OBJ)/ssim_dropin.o: $(SRC)/ssim_dropin.cpp $(SRC)/ssim_internal.h include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-hip.h include/rmgr/ssim-version.h
 	@mkdir -p $(OBJ)
 	$(CXX) -std=c++98 -pedantic -O2 -fPIC -Wall -Wextra -Iinclude -c $< -o $@
 
@@ -56,7 +67,7 @@ install: lib
 	install -d $(DESTDIR)$(PREFIX)/include/rmgr $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/bin $(DESTDIR)$(PREFIX)/lib/pkgconfig
 	install -m 644 include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-version.h include/rmgr/ssim-hip.h $(DESTDIR)$(PREFIX)/include/rmgr/
 	install -m 755 $(OUT)/librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/
-	install -m 644 $(OUT)/librmgr-ssim.a $(DESTDIR)$(PREFIX)/lib/
+	install -m 644 $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(DESTDIR)$(PREFIX)/lib/
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim.so
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim-openmp.so
 	install -m 755 $(BIN)/rmgr-ssim $(DESTDIR)$(PREFIX)/bin/

@@ -200,7 +200,12 @@ bool decode_png(const Bytes& f, Image& img, std::string& err)
         pos += 12 + len;
     }
     if (interlace) { err = "interlaced PNG is not supported"; return false; }
-    if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) { err = "unsupported PNG bit depth"; return false; }
+    // bit depths the PNG specification allows per colour type; anything else (0, 3, 5, 6, 7, 32 ...) is refused
+    // before any buffer is sized or any shift is formed
+    const bool depth_ok = (ctype == 0) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                        : (ctype == 3) ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                        : (ctype == 2 || ctype == 4 || ctype == 6) ? (depth == 8 || depth == 16) : false;
+    if (!depth_ok) { err = "unsupported PNG colour type / bit depth"; return false; }
     const int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || !sane_size(w, h, size_t(samples) * 2) || idat.size() < 6) { err = "unsupported or corrupt PNG"; return false; }
     const size_t bpp = std::max<size_t>(1, size_t(samples) * depth / 8), rowBytes = (size_t(w) * samples * depth + 7) / 8;
@@ -924,40 +929,144 @@ int report(rmgr_int32_t rc)
     return EXIT_FAILURE;
 }
 
-// The three modes of the reference's compute_ssims() (src/ssim-cli.cpp:130-213), same printf formats.
-int compute_ssims(const Image& a, const Image& b, int onlyChannel, bool luminance, float* map, int mapChannels)
+// ---- the command, as data ----
+// What to compare: every channel (the default), one channel (-0 .. -3) or the BT.601 luminance (-y).  Behaviour and
+// printed text are the reference tool's (src/ssim-cli.cpp:130-213, :216-389); the structure is this file's own.
+struct Selection {
+    enum Kind { EVERY_CHANNEL, ONE_CHANNEL, LUMA } kind;
+    int channel;
+};
+
+struct Command {
+    Selection   what;
+    const char* file[2];
+    const char* mapFile;     // NULL: no map requested
+};
+
+const struct { const char* flag; Selection sel; } kFlags[] = {
+    {"-0", {Selection::ONE_CHANNEL, 0}}, {"-1", {Selection::ONE_CHANNEL, 1}}, {"-2", {Selection::ONE_CHANNEL, 2}},
+    {"-3", {Selection::ONE_CHANNEL, 3}}, {"-y", {Selection::LUMA, 0}},
+};
+
+// argv -> Command.  false: usage error (the message has been printed).
+bool parse_command(int argc, char* argv[], Command& cmd)
 {
-    const int w = a.width, h = a.height, ch = a.channels;
-    if (ch < 3 && luminance) onlyChannel = 0;
-    if (onlyChannel >= 0) {
+    if (argc < 3 || argc > 5) { print_help(stderr); return false; }
+    cmd.what.kind = Selection::EVERY_CHANNEL;
+    cmd.what.channel = 0;
+    int first = 1;
+    if (argc >= 4 && argv[1][0] == '-') {
+        size_t k = 0;
+        while (k < sizeof(kFlags) / sizeof(kFlags[0]) && strcmp(argv[1], kFlags[k].flag) != 0) ++k;
+        if (k == sizeof(kFlags) / sizeof(kFlags[0])) { fprintf(stderr, "Unknown option: %s\n", argv[1]); return false; }
+        cmd.what = kFlags[k].sel;
+        first = 2;
+    }
+    cmd.file[0] = argv[first];
+    cmd.file[1] = argv[first + 1];
+    cmd.mapFile = (argc - first == 3) ? argv[first + 2] : NULL;
+    return true;
+}
+
+// Map file formats by extension; `anyChannels` false = only 1 or 3 channels can be stored.
+enum MapFormat { MAP_TGA, MAP_BMP, MAP_PNG, MAP_PFM, MAP_PNM };
+const struct { const char* ext; MapFormat fmt; bool anyChannels; const char* label; } kMapFormats[] = {
+    {".bmp", MAP_BMP, true, "BMP"}, {".png", MAP_PNG, true, "PNG"}, {".tga", MAP_TGA, true, "TGA"},
+    {".pgm", MAP_PNM, false, "PNM"}, {".ppm", MAP_PNM, false, "PNM"}, {".pnm", MAP_PNM, false, "PNM"}, {".pfm", MAP_PFM, false, "PFM"},
+};
+
+// Runs the selected comparison and prints it in the reference's formats ("% 7.4f", "Channel %u: ...", "Average  : ...").
+int compare(const Image& a, const Image& b, Selection what, float* map, int mapChannels)
+{
+    const rmgr_uint32_t w = rmgr_uint32_t(a.width), h = rmgr_uint32_t(a.height), ch = rmgr_uint32_t(a.channels);
+    const ptrdiff_t pitch = ptrdiff_t(w) * ch;
+    if (what.kind == Selection::LUMA && ch < 3)            // nothing to weigh: the first channel is the luminance
+        what.kind = Selection::ONE_CHANNEL, what.channel = 0;
+    std::vector<float> value(what.kind == Selection::EVERY_CHANNEL ? ch : 1u);
+    rmgr_int32_t rc;
+    switch (what.kind) {
+    case Selection::ONE_CHANNEL: {
         rmgr_ssim_Params p;
         memset(&p, 0, sizeof(p));
-        p.width = rmgr_uint32_t(w); p.height = rmgr_uint32_t(h);
-        rmgr_ssim_init_interleaved(&p.imgA, &a.px[0], ptrdiff_t(w) * ch, rmgr_uint32_t(ch), rmgr_uint32_t(onlyChannel));
-        rmgr_ssim_init_interleaved(&p.imgB, &b.px[0], ptrdiff_t(w) * ch, rmgr_uint32_t(ch), rmgr_uint32_t(onlyChannel));
+        p.width = w; p.height = h;
+        rmgr_ssim_init_interleaved(&p.imgA, &a.px[0], pitch, ch, rmgr_uint32_t(what.channel));
+        rmgr_ssim_init_interleaved(&p.imgB, &b.px[0], pitch, ch, rmgr_uint32_t(what.channel));
         p.ssimMap = map; p.ssimStep = mapChannels; p.ssimStride = ptrdiff_t(w) * mapChannels;
-        float ssim;
-        const rmgr_int32_t rc = rmgr_ssim_compute_ssim(&ssim, &p, NULL);
-        if (rc != 0) return report(rc);
-        printf("% 7.4f\n", ssim);
-    } else if (luminance) {
-        float ssim;
-        const rmgr_int32_t rc = rmgr_ssim_hip_compute_ssim_luminance_host(NULL, &ssim, &a.px[0], ptrdiff_t(w) * ch, &b.px[0], ptrdiff_t(w) * ch,
-                                                                          rmgr_uint32_t(w), rmgr_uint32_t(h), rmgr_uint32_t(ch), map);
-        if (rc != 0) return report(rc);
-        printf("% 7.4f\n", ssim);
-    } else {
-        std::vector<float> ssim(ch);
-        const rmgr_int32_t rc = rmgr_ssim_hip_compute_ssim_channels_host(NULL, &ssim[0], &a.px[0], ptrdiff_t(w) * ch, &b.px[0], ptrdiff_t(w) * ch,
-                                                                         rmgr_uint32_t(w), rmgr_uint32_t(h), rmgr_uint32_t(ch), map);
-        if (rc != 0) return report(rc);
-        float average = 0.0f;
-        for (int c = 0; c < ch; ++c) {
-            printf("Channel %u: % 7.4f\n", unsigned(c), ssim[c]);
-            average += ssim[c];
-        }
-        printf("Average  : % 7.4f\n", average / ch);
+        rc = rmgr_ssim_compute_ssim(&value[0], &p, NULL);
+        break;
     }
+    case Selection::LUMA:
+        rc = rmgr_ssim_hip_compute_ssim_luminance_host(NULL, &value[0], &a.px[0], pitch, &b.px[0], pitch, w, h, ch, map);
+        break;
+    default:
+        rc = rmgr_ssim_hip_compute_ssim_channels_host(NULL, &value[0], &a.px[0], pitch, &b.px[0], pitch, w, h, ch, map);
+        break;
+    }
+    if (rc != 0) return report(rc);
+    if (what.kind != Selection::EVERY_CHANNEL) {
+        printf("% 7.4f\n", value[0]);
+        return EXIT_SUCCESS;
+    }
+    float total = 0.0f;
+    for (rmgr_uint32_t c = 0; c < ch; ++c) {
+        printf("Channel %u: % 7.4f\n", unsigned(c), value[c]);
+        total += value[c];
+    }
+    printf("Average  : % 7.4f\n", total / float(ch));
+    return EXIT_SUCCESS;
+}
+
+// Stores the map: PFM keeps the floats (bottom row first, little endian, src/ssim-cli.cpp:355-374); every other
+// format stores max(0, v) * 255 truncated to 8 bits (:341-342).
+int save_map(const char* path, const std::vector<float>& map, int w, int h, int channels)
+{
+    const char* ext = strrchr(path, '.');
+    MapFormat fmt = MAP_TGA;
+    if (!ext) {
+        fprintf(stderr, "Cannot deduce file format from extension, saving as tga\n");
+    } else {
+        size_t k = 0;
+        while (k < sizeof(kMapFormats) / sizeof(kMapFormats[0]) && strcasecmp(ext, kMapFormats[k].ext) != 0) ++k;
+        if (k == sizeof(kMapFormats) / sizeof(kMapFormats[0])) return EXIT_FAILURE;         // unknown extension
+        fmt = kMapFormats[k].fmt;
+        if (!kMapFormats[k].anyChannels && channels != 1 && channels != 3) {
+            fprintf(stderr, "%s images can only contain 1 or 3 channels but the map contains %d channels\n", kMapFormats[k].label, channels);
+            return EXIT_FAILURE;
+        }
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) { fprintf(stderr, "Failed to open file \"%s\" for writing\n", path); return EXIT_FAILURE; }
+    bool ok = true;
+    if (fmt == MAP_PFM) {
+        fprintf(f, "P%c\n%d %d\n-1.0\n", channels == 1 ? 'f' : 'F', w, h);
+        const size_t row = size_t(w) * channels;
+        for (int y = h; --y >= 0;) ok = ok && fwrite(&map[y * row], sizeof(float), row, f) == row;
+    } else {
+        Bytes q(map.size());
+        for (size_t i = 0; i < map.size(); ++i) q[i] = (unsigned char)(std::max(0.0f, map[i]) * 255.0f);
+        switch (fmt) {
+        case MAP_PNG: ok = write_png(f, w, h, channels, &q[0]); break;
+        case MAP_BMP: ok = write_bmp(f, w, h, channels, &q[0]); break;
+        case MAP_TGA: ok = write_tga(f, w, h, channels, &q[0]); break;
+        default:
+            fprintf(f, "P%c\n%d %d\n255\n", channels == 1 ? '5' : '6', w, h);
+            ok = fwrite(&q[0], 1, q.size(), f) == q.size();
+        }
+    }
+    fclose(f);
+    if (!ok) { fprintf(stderr, "Error writing to file \"%s\"\n", path); return EXIT_FAILURE; }
+    return EXIT_SUCCESS;
+}
+
+// test hook (not in the reference): decode an image with the built-in codecs, dump the raw pixels
+int decode_to_file(const char* in, const char* out)
+{
+    Image img;
+    if (!load_image(in, img)) return EXIT_FAILURE;
+    FILE* f = fopen(out, "wb");
+    if (!f || fwrite(&img.px[0], 1, img.px.size(), f) != img.px.size()) return EXIT_FAILURE;
+    fclose(f);
+    printf("%d %d %d\n", img.width, img.height, img.channels);
     return EXIT_SUCCESS;
 }
 
@@ -966,91 +1075,32 @@ int compute_ssims(const Image& a, const Image& b, int onlyChannel, bool luminanc
 static int run(int argc, char* argv[])
 {
     if (argc == 2 && (!strcmp(argv[1], "-h") || !strcmp(argv[1], "--help"))) { print_help(stdout); return EXIT_SUCCESS; }
-    if (argc == 4 && !strcmp(argv[1], "--decode")) {
-        // test hook (not in the reference): decode an image with the built-in codecs, dump the raw pixels
-        Image img;
-        if (!load_image(argv[2], img)) return EXIT_FAILURE;
-        FILE* f = fopen(argv[3], "wb");
-        if (!f || fwrite(&img.px[0], 1, img.px.size(), f) != img.px.size()) return EXIT_FAILURE;
-        fclose(f);
-        printf("%d %d %d\n", img.width, img.height, img.channels);
-        return EXIT_SUCCESS;
-    }
-    if (argc < 3 || argc > 5) { print_help(stderr); return EXIT_FAILURE; }
+    if (argc == 4 && !strcmp(argv[1], "--decode")) return decode_to_file(argv[2], argv[3]);
+    Command cmd;
+    if (!parse_command(argc, argv, cmd)) return EXIT_FAILURE;
 
-    int onlyChannel = -1, filesIndex = 1;
-    bool luminance = false;
-    if (argc >= 4 && argv[1][0] == '-') {
-        const char* opt = argv[1];
-        if (!strcmp(opt, "-0")) onlyChannel = 0;
-        else if (!strcmp(opt, "-1")) onlyChannel = 1;
-        else if (!strcmp(opt, "-2")) onlyChannel = 2;
-        else if (!strcmp(opt, "-3")) onlyChannel = 3;
-        else if (!strcmp(opt, "-y")) luminance = true;
-        else { fprintf(stderr, "Unknown option: %s\n", opt); return EXIT_FAILURE; }
-        filesIndex = 2;
+    Image img[2];
+    for (int i = 0; i < 2; ++i)
+        if (!load_image(cmd.file[i], img[i])) return EXIT_FAILURE;
+    if (img[0].width != img[1].width || img[0].height != img[1].height) {
+        fprintf(stderr, "Images do not have the same dimensions: %ux%u vs %ux%u\n", img[0].width, img[0].height, img[1].width, img[1].height);
+        return EXIT_FAILURE;
     }
-    const char* path1 = argv[filesIndex];
-    const char* path2 = argv[filesIndex + 1];
-    const char* mapPath = (argc - filesIndex == 3) ? argv[filesIndex + 2] : NULL;
-
-    Image img1, img2;
-    if (!load_image(path1, img1) || !load_image(path2, img2)) return EXIT_FAILURE;
+    if (img[0].channels != img[1].channels) {
+        fprintf(stderr, "Images do not have the same number of channels: %u vs %u\n", img[0].channels, img[1].channels);
+        return EXIT_FAILURE;
+    }
+    if (cmd.what.kind == Selection::ONE_CHANNEL && cmd.what.channel >= img[0].channels) {
+        fprintf(stderr, "Cannot compute SSIM for channel %u, images have only %u channels\n", cmd.what.channel, img[0].channels);
+        return EXIT_FAILURE;
+    }
 
     std::vector<float> map;
-    int mapChannels = 0;
-    if (mapPath) {
-        mapChannels = (onlyChannel >= 0 || luminance) ? 1 : img1.channels;
-        map.resize(size_t(img1.width) * img1.height * mapChannels);
-    }
-
-    int retval = EXIT_FAILURE;
-    if (img1.width != img2.width || img1.height != img2.height)
-        fprintf(stderr, "Images do not have the same dimensions: %ux%u vs %ux%u\n", img1.width, img1.height, img2.width, img2.height);
-    else if (img1.channels != img2.channels)
-        fprintf(stderr, "Images do not have the same number of channels: %u vs %u\n", img1.channels, img2.channels);
-    else if (onlyChannel >= 0 && onlyChannel >= img1.channels)
-        fprintf(stderr, "Cannot compute SSIM for channel %u, images have only %u channels\n", onlyChannel, img1.channels);
-    else
-        retval = compute_ssims(img1, img2, onlyChannel, luminance, mapPath ? &map[0] : NULL, mapChannels);
-
-    if (retval == EXIT_SUCCESS && mapPath) {
-        const char* ext = strrchr(mapPath, '.');
-        enum { TGA, BMP, PNG, PFM, PNM } fmt = TGA;
-        if (!ext) fprintf(stderr, "Cannot deduce file format from extension, saving as tga\n");
-        else if (!strcasecmp(ext, ".bmp")) fmt = BMP;
-        else if (!strcasecmp(ext, ".png")) fmt = PNG;
-        else if (!strcasecmp(ext, ".tga")) fmt = TGA;
-        else if (!strcasecmp(ext, ".pgm") || !strcasecmp(ext, ".ppm") || !strcasecmp(ext, ".pnm")) fmt = PNM;
-        else if (!strcasecmp(ext, ".pfm")) {
-            fmt = PFM;
-            if (mapChannels != 1 && mapChannels != 3) { fprintf(stderr, "PFM images can only contain 1 or 3 channels but the map contains %d channels\n", mapChannels); retval = EXIT_FAILURE; }
-        } else retval = EXIT_FAILURE;
-        if (fmt == PNM && mapChannels != 1 && mapChannels != 3) { fprintf(stderr, "PNM images can only contain 1 or 3 channels but the map contains %d channels\n", mapChannels); retval = EXIT_FAILURE; }
-
-        if (retval == EXIT_SUCCESS) {
-            FILE* f = fopen(mapPath, "wb");
-            if (!f) { fprintf(stderr, "Failed to open file \"%s\" for writing\n", mapPath); return EXIT_FAILURE; }
-            const int w = img1.width, h = img1.height;
-            bool ok = true;
-            if (fmt == PFM) {
-                // raw floats, bottom row first, little endian (src/ssim-cli.cpp:355-374)
-                fprintf(f, "P%c\n%d %d\n-1.0\n", mapChannels == 1 ? 'f' : 'F', w, h);
-                const size_t stride = size_t(w) * mapChannels;
-                for (int y = h; --y >= 0;) ok = ok && fwrite(&map[y * stride], sizeof(float), stride, f) == stride;
-            } else {
-                Bytes map8(map.size());
-                for (size_t i = 0; i < map.size(); ++i) map8[i] = (unsigned char)(std::max(0.0f, map[i]) * 255.0f);   // src/ssim-cli.cpp:341-342
-                if (fmt == PNG) ok = write_png(f, w, h, mapChannels, &map8[0]);
-                else if (fmt == BMP) ok = write_bmp(f, w, h, mapChannels, &map8[0]);
-                else if (fmt == TGA) ok = write_tga(f, w, h, mapChannels, &map8[0]);
-                else { fprintf(f, "P%c\n%d %d\n255\n", mapChannels == 1 ? '5' : '6', w, h); ok = fwrite(&map8[0], 1, map8.size(), f) == map8.size(); }
-            }
-            if (!ok) { fprintf(stderr, "Error writing to file \"%s\"\n", mapPath); retval = EXIT_FAILURE; }
-            fclose(f);
-        }
-    }
-    return retval;
+    const int mapChannels = !cmd.mapFile ? 0 : (cmd.what.kind == Selection::EVERY_CHANNEL ? img[0].channels : 1);
+    if (cmd.mapFile) map.resize(size_t(img[0].width) * img[0].height * mapChannels);
+    const int rc = compare(img[0], img[1], cmd.what, cmd.mapFile ? &map[0] : NULL, mapChannels);
+    if (rc != EXIT_SUCCESS || !cmd.mapFile) return rc;
+    return save_map(cmd.mapFile, map, img[0].width, img[0].height, mapChannels);
 }
 
 int main(int argc, char* argv[])

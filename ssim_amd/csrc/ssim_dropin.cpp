@@ -8,6 +8,7 @@
 #include <rmgr/ssim-openmp.h>
 #include <rmgr/ssim-hip.h>
 #include <rmgr/ssim-version.h>
+#include "ssim_internal.h"
 
 #include <errno.h>
 #include <stdlib.h>
@@ -86,21 +87,18 @@ extern "C" rmgr_int32_t rmgr_ssim_compute_ssim_openmp(float* ssim, const rmgr_ss
 namespace rmgr { namespace ssim
 {
 
-// Values of the reference's test-only selector (src/ssim_internal.h:41-51), extended by IMPL_HIP.
-enum Implementation
+// The reference's test-only selector (src/ssim.cpp:808-896); semantics in ssim_internal.h.
+unsigned select_impl(Implementation desiredImpl) RMGR_NOEXCEPT
 {
-    IMPL_AUTO = 0, IMPL_GENERIC = 1, IMPL_SSE = 2, IMPL_SSE2 = 3, IMPL_AVX = 4, IMPL_FMA = 5, IMPL_AVX512 = 6, IMPL_NEON = 7,
-    IMPL_HIP = 8
-};
-
-// Reports which implementations exist as a bit mask.  Only AUTO and HIP do: there is no CPU
-// arithmetic in this library, so asking for a CPU ISA reports it as unsupported, which is how the
-// reference's tests skip an ISA the machine lacks (tests/rmgr-ssim-tests.cpp:231-232).
-unsigned select_impl(Implementation) RMGR_NOEXCEPT
-{
-    rmgr_int32_t devices = 0;
-    rmgr_ssim_hip_get_device_count(&devices);
-    return (devices > 0) ? ((1u << IMPL_AUTO) | (1u << IMPL_HIP)) : 0u;
+    const unsigned supported = (1u << IMPL_AUTO) | (1u << IMPL_GENERIC) | (1u << IMPL_SSE) | (1u << IMPL_SSE2) |
+                               (1u << IMPL_AVX) | (1u << IMPL_FMA) | (1u << IMPL_HIP);
+    rmgr_int32_t mode;
+    switch (desiredImpl) {
+    case IMPL_AUTO: case IMPL_FMA: case IMPL_HIP: mode = RMGR_SSIM_HIP_MODE_EXACT;   break;
+    default:                                      mode = RMGR_SSIM_HIP_MODE_UNFUSED; break;   // incl. the unsupported ones: generic arithmetic
+    }
+    // NULL context = the process-wide default one the drop-in calls run on; fails when no device is usable
+    return (rmgr_ssim_hip_set_mode(NULL, mode) == 0) ? supported : 0u;
 }
 
 int32_t compute_ssim(float* ssim, const GeneralParams& params, const ThreadPool* threadPool) RMGR_NOEXCEPT

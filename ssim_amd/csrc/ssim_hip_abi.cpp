@@ -581,7 +581,20 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode) RMGR_NOEXCEPT
 {
-    if (!c || mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_UNFUSED) return EINVAL;
+    if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_UNFUSED) return EINVAL;
+    if (!c) {
+        // the process-wide default context of the drop-in entry points (what rmgr::ssim::select_impl switches)
+        int rc = 0;
+        c = default_context(&rc);
+        if (rc) return rc;
+        if (!c) return ENODEV;
+        std::lock_guard<std::mutex> guard(c->lock);
+#if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
+        if (mode == RMGR_SSIM_HIP_MODE_EXACT || mode == RMGR_SSIM_HIP_MODE_UNFUSED) mode = RMGR_SSIM_HIP_MODE_DOUBLE;   // a double build stays double
+#endif
+        c->mode = mode;
+        return 0;
+    }
     c->mode = mode;
     return 0;
 }

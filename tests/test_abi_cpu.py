@@ -198,6 +198,25 @@ def test_install_layout_and_reference_link_line(tmp_path):
     exe_static = tmp_path / "client_static"
     subprocess.run(["g++", "-std=c++98", "-I", str(prefix / "include"), os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe_static),
                     str(prefix / "lib" / "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    # ... and so does the reference's pair of archives by name (CMakeLists.txt:205, :229), forced static
+    assert (prefix / "lib" / "librmgr-ssim-openmp.a").exists()
+    exe_pair = tmp_path / "client_static_pair"
+    subprocess.run(["g++", "-std=c++98", "-I", str(prefix / "include"), os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe_pair),
+                    "-L", str(prefix / "lib"), "-Wl,-Bstatic", "-lrmgr-ssim-openmp", "-lrmgr-ssim", "-Wl,-Bdynamic",
+                    "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_select_impl_reports_nothing_without_a_device(lib):
+    """rmgr::ssim::select_impl (src/ssim.cpp:808) returns the mask of usable implementations: none when there is no GPU
+    (the reference's tests then skip, tests/rmgr-ssim-tests.cpp:231-232); and the NULL-context set_mode it relies on
+    says ENODEV."""
+    fn = getattr(lib, "_ZN4rmgr4ssim11select_implENS0_14ImplementationE")
+    fn.argtypes, fn.restype = [ctypes.c_int], ctypes.c_uint
+    for impl in range(9):
+        assert fn(impl) == 0
+    assert lib.rmgr_ssim_hip_set_mode(None, 0) == errno.ENODEV
+    assert lib.rmgr_ssim_hip_set_mode(None, 9) == errno.EINVAL
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")

@@ -249,6 +249,34 @@ def test_decoders_reject_mutated_files_without_crashing(tmp_path, manifest):
     assert r.returncode == 1 and b"PNG" in r.stderr
 
 
+def test_png_bit_depths_outside_the_specification_are_refused(tmp_path):
+    """depth 0 sized a row of 0 bytes and divided by (1 << 0) - 1 (SIGSEGV / SIGFPE), depths 3, 5, 6, 7
+    formed negative shifts.  Only the depths the PNG specification allows per colour type may pass the header check;
+    the legal sub-byte depths must still decode."""
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    def png(depth, ctype, w=8, h=2, plte=False):
+        row = bytes([0]) + bytes(max(1, (w * {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}.get(ctype, 1) * max(depth, 1) + 7) // 8))
+        body = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+        if plte:
+            body += chunk(b"PLTE", bytes(range(48)))
+        return body + chunk(b"IDAT", zlib.compress(row * h)) + chunk(b"IEND", b"")
+
+    out = str(tmp_path / "o.raw")
+    bad = [(0, 0), (3, 0), (5, 0), (6, 0), (7, 0), (32, 0), (0, 3), (3, 3), (16, 3), (1, 2), (4, 2), (0, 2), (2, 4), (4, 6), (0, 6), (8, 1), (8, 5)]
+    for depth, ctype in bad:
+        path = str(tmp_path / ("bad_%d_%d.png" % (depth, ctype)))
+        open(path, "wb").write(png(depth, ctype, plte=ctype == 3))
+        r = subprocess.run([CLI, "--decode", path, out], capture_output=True, timeout=30)
+        assert r.returncode == 1 and b"PNG" in r.stderr, (depth, ctype, r.returncode, r.stderr[-200:])
+    for depth, ctype in [(1, 0), (2, 0), (4, 0), (8, 0), (16, 0), (1, 3), (2, 3), (4, 3), (8, 3), (8, 2), (16, 2), (8, 4), (16, 6)]:
+        path = str(tmp_path / ("ok_%d_%d.png" % (depth, ctype)))
+        open(path, "wb").write(png(depth, ctype, plte=ctype == 3))
+        r = subprocess.run([CLI, "--decode", path, out], capture_output=True, timeout=30)
+        assert r.returncode == 0, (depth, ctype, r.stderr[-200:])
+
+
 def bt601(img):
     x = img.astype(np.uint32)
     return ((x[:, :, 0] * 19595 + x[:, :, 1] * 38470 + x[:, :, 2] * 7471 + 32768) >> 16).astype(np.uint8)

@@ -226,3 +226,31 @@ def test_fast_mode_meets_the_reference_test_tolerances(gpu_ctx, manifest):
     assert worst_g < 6e-7, worst_g
     assert worst_gf < 1.3e-6, worst_gf
     assert worst_p < 3e-4, worst_p
+
+
+def test_select_impl_switches_the_arithmetic_of_the_dropin_call(manifest):
+    """The reference's test-only selector (src/ssim_internal.h:41-53, src/ssim.cpp:808-896) keeps its meaning: after
+    select_impl(IMPL_AVX) -- or GENERIC / SSE / SSE2 -- the unchanged rmgr_ssim_compute_ssim returns the reference AVX
+    path's bits, after select_impl(IMPL_FMA) the FMA path's; AVX-512 and NEON are reported unsupported."""
+    lib = ssim_amd.load_library()
+    fn = getattr(lib, "_ZN4rmgr4ssim11select_implENS0_14ImplementationE")
+    fn.argtypes, fn.restype = [ctypes.c_int], ctypes.c_uint
+    AUTO, GENERIC, SSE, SSE2, AVX, FMA, AVX512, NEON, HIP = range(9)
+    names = [n for n in image_entries(manifest) if manifest[n]["fma"]["ssim_hex"] != manifest[n]["avx"]["ssim_hex"]][:4]
+    assert names
+    try:
+        for impl, key in ((AVX, "avx"), (FMA, "fma"), (GENERIC, "avx"), (SSE2, "avx"), (AUTO, "fma"), (SSE, "avx"), (HIP, "fma")):
+            mask = fn(impl)
+            assert mask & (1 << impl), (impl, mask)
+            assert not mask & ((1 << AVX512) | (1 << NEON))
+            for n in names:
+                a, b = load_pair(manifest[n])
+                v, m = ssim_amd.compute_ssim(a, b, want_map=True)
+                assert f32_hex(v) == manifest[n][key]["ssim_hex"], (impl, n)
+                import hashlib
+                assert hashlib.sha256(m.tobytes()).hexdigest() == manifest[n][key]["map_sha256"], (impl, n)
+        assert not fn(AVX512) & (1 << AVX512)          # unsupported; the generic arithmetic is selected, as in the reference
+        a, b = load_pair(manifest[names[0]])
+        assert f32_hex(ssim_amd.compute_ssim(a, b)[0]) == manifest[names[0]]["avx"]["ssim_hex"]
+    finally:
+        fn(AUTO)

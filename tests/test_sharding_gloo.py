@@ -19,7 +19,7 @@ def image_sum(i):
     return oracle.ssim_f32(a, b)[1]
 
 
-def worker(rank, world, port, out_dir):
+def worker(rank, world, port, out_dir, strong_total=0):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -28,8 +28,13 @@ def worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, last = sharding.shard_range(rank, world, PAIRS_PER_RANK)
-    sums_all = torch.zeros(world * PAIRS_PER_RANK, dtype=torch.float64)
+    if strong_total:      # bench.py --scaling strong: a fixed batch split over the ranks (uneven shares allowed)
+        first, last = sharding.split_batch(strong_total, world)[rank]
+        total = strong_total
+    else:                 # --scaling weak: a fixed share per rank
+        first, last = sharding.shard_range(rank, world, PAIRS_PER_RANK)
+        total = world * PAIRS_PER_RANK
+    sums_all = torch.zeros(total, dtype=torch.float64)
     work = torch.zeros_like(sums_all)
     for i in range(first, last):
         sums_all[i] = image_sum(i)
@@ -51,6 +56,47 @@ def test_two_ranks_get_identical_complete_results(tmp_path):
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
         assert np.array_equal(got.view(np.uint32), single.view(np.uint32)), r
+
+
+def test_strong_scaling_split_with_uneven_shares(tmp_path):
+    """BASELINE.json configs[3] shape (a fixed batch over N ranks) with a batch that does not divide evenly."""
+    import torch.multiprocessing as mp
+    world, total = 2, 5
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(worker, args=(world, port, str(tmp_path), total), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import ssim_amd
+    single = ssim_amd.finalize(np.array([image_sum(i) for i in range(total)]), W, H)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
+        assert np.array_equal(got.view(np.uint32), single.view(np.uint32)), r
+
+
+def test_bench_builds_its_own_rank_launcher():
+    """`python bench.py --gpus N` must not depend on an outside launcher: it starts
+    torch.distributed.run itself, as a child process, on 127.0.0.1."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--print-launch", "--gpus", "4", "--steps", "3", "--scaling", "strong", "--workload", "1080p"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    cmd = r.stdout.split()
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--print-launch" not in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index(bench) + 1:] == ["--gpus", "4", "--steps", "3", "--scaling", "strong", "--workload", "1080p"]
+
+
+def test_bench_two_ranks_fail_only_at_the_missing_device():
+    """On a box without GPUs the self-launched 2-rank run must get as far as every rank looking for its device."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("checks the no-device behaviour")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("no HIP device visible") == 2, r.stderr[-1500:]
+    assert "metric" not in r.stdout
 
 
 def test_shard_helpers():
