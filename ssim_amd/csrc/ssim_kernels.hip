@@ -437,9 +437,15 @@ struct Slot2 {
 
 enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 
-template <int MODE, bool MAP>
+// QREG (MODE_FAST): the (a*a, b*b) plane is not staged in LDS; the products are formed in registers from the (a,b)
+// window (+12 packed multiplies, -7 of 20 window reads per lane-row).  Round-2 experiment on the separable mode's LDS
+// co-limit (profiles/r02_fast_lds_attack.md): LDS issue stalls 39 M -> 12 M per launch, VALU-busy 72 -> 77 %, +3.3...4.4 %;
+// bit-identical results.  Storing the ab plane once and running its two columns as scalar streams was also measured
+// (alone -1...-5 %, together with this +2...3 %) and dropped.  Tuning variant 2 selects the round-1 layout (QREG off).
+template <int MODE, bool MAP, bool QREG = false>
 __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 {
+    static_assert(!QREG || MODE == MODE_FAST, "the register-product layout exists for MODE_FAST only");
     constexpr int PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
     constexpr int NLOAD = 3;                         // pixels each lane stages per row
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
@@ -449,6 +455,9 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     __shared__ __attribute__((aligned(16))) Slot2 ring[2];
 
     const int lane = threadIdx.x;
+    // the separable taps as six scalars (an array inside the kernel argument block, passed on by reference, can end up
+    // in scratch memory when scalar and packed streams both use it)
+    const float gf[6] = {args.gf[0], args.gf[1], args.gf[2], args.gf[3], args.gf[4], args.gf[5]};
     const Strip st = strip_setup(args, Slot2::STRIP_W);
     const PairDesc& pd = st.pd;
     // 32-bit coordinates (fits_strip2() on the host guarantees the ranges): row bookkeeping stays on the
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             const float x = a * b;                            // multiply (exact for 8-bit inputs)
             const int p = sp[t];
             s.ab[p] = ab;
-            s.q[p] = ab * ab;
+            if constexpr (!QREG) s.q[p] = ab * ab;
             xf[2 * p] = x;                          // xx[p].lo
             xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
         }
@@ -598,10 +607,12 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
         // Whole 16-byte reads only: 8-byte reads at this 16-byte lane stride are 2-way bank conflicts.  The three
         // end entries the wide form loads without need are kept alive until their planes are consumed (see load_ab).
+        if constexpr (!QREG) {
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
-            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+            for (int t = 0; t < 7; ++t) {
+                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
@@ -613,19 +624,24 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if constexpr (EXACT) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
-            else                 blur_separable<true>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], args.gf);
+            else                 blur_separable<true>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], gf);
         }
         // (4) the (a*a,b*b) streams
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (QREG) {                           // (a*a, b*b) of the window pixels, in registers
+#pragma unroll
+            for (int k = 1; k <= 12; ++k) wq[k] = wab[k] * wab[k];
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int m = 6 + c;
             const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
                      q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
             if constexpr (EXACT) blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
-            else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, args.gf);
+            else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, gf);
         }
-        asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
+        if constexpr (!QREG) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
+        else                 asm volatile("" :: "v"(wxx[0]));
         // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
         //     with more than 15 LDS operations in flight the compiler can only drain them all.
         __builtin_amdgcn_sched_barrier(0);
@@ -638,7 +654,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
             if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
-            else                 blur_separable(accX, wxx[6], x1, x2, x3, x4, x5, args.gf);
+            else                 blur_separable(accX, wxx[6], x1, x2, x3, x4, x5, gf);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -919,12 +935,12 @@ __global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restri
         sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = sh[0];
 }
 
-template <int MODE>
+template <int MODE, bool QREG = false>
 hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
-    if (map) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, true>), grid, block, 0, stream, ka);
-    else     hipLaunchKernelGGL((ssim_strip2_kernel<MODE, false>), grid, block, 0, stream, ka);
+    if (map) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, true, QREG>), grid, block, 0, stream, ka);
+    else     hipLaunchKernelGGL((ssim_strip2_kernel<MODE, false, QREG>), grid, block, 0, stream, ka);
     return hipGetLastError();
 }
 
@@ -1148,7 +1164,9 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     switch (mode) {
     case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
     case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
-    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
+    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)
+                           : variant == 2 ? launch_strip2<MODE_FAST, false>(geo, ka, map, stream)    // the round-1 LDS layout
+                                          : launch_strip2<MODE_FAST, true>(geo, ka, map, stream);    break;
     case MODE_DOUBLE:  err = launch_strip1<MODE_DOUBLE>(geo, ka, map, stream); break;
     default:           return hipErrorInvalidValue;
     }

@@ -2,7 +2,7 @@
 """Minimal torch-free workload for rocprofv3 counter passes: the bench.py batch (N distinct 4096^2
 pairs resident in HBM, global SSIM only, or with the map) enqueued K times through the C ABI.
 
-usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width] [rgb=0]
+usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width] [rgb=0] [variant=0]
 rgb=1: every pair is an interleaved RGB image pair (step 3) and all three channels go into the launch (3 x pairs results)
 """
 import os
@@ -22,6 +22,7 @@ def main():
     h = arg(6, w)
     rgb = arg(7, 0)
     ctx = ssim_amd.Context(0, mode=mode)
+    ctx.set_tuning(0, arg(8, 0))
     n = pairs * (3 if rgb else 1)
     params = (ssim_amd.Params * n)()
     keep = []
@@ -35,8 +36,8 @@ def main():
             for c in range(3):
                 params[3 * i + c] = ssim_amd.make_params(w, h, da.ptr + c, 3, 3 * w, db.ptr + c, 3, 3 * w)
             continue
-        a, b = synth.pair_numpy(w, h, synth.BASE_SEED + i)
-        da, db = ctx.upload(a), ctx.upload(b)
+        da, db = ctx.alloc(w * h), ctx.alloc(w * h)
+        ctx.synth_pair(da.ptr, w, db.ptr, w, w, h, synth.BASE_SEED + i)
         dm = ctx.alloc(4 * w * h) if want_map else None
         keep += [da, db, dm]
         params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr if dm else None, 1, w)
