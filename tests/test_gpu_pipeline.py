@@ -254,3 +254,21 @@ def test_select_impl_switches_the_arithmetic_of_the_dropin_call(manifest):
         assert f32_hex(ssim_amd.compute_ssim(a, b)[0]) == manifest[names[0]]["avx"]["ssim_hex"]
     finally:
         fn(AUTO)
+
+
+def test_fast_mode_lds_layouts_are_bit_identical(gpu_ctx, oracle):
+    """MODE_FAST forms (a*a, b*b) in registers by default (round 2); tuning variant 2 is the round-1 layout that stages
+    the plane in LDS, variant 1 the one-column kernel.  Same operations on the same values: identical bits."""
+    a, b = oracle.synth_pair(700, 300, 0x5EED + 9)
+    gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+    try:
+        ref = None
+        for variant in (0, 2, 1):
+            gpu_ctx.set_tuning(0, variant)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            if ref is None:
+                ref = (v, m)
+            assert f32_hex(v) == f32_hex(ref[0]) and np.array_equal(m.view(np.uint32), ref[1].view(np.uint32)), variant
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
