@@ -465,18 +465,20 @@ def main():
         hv, _ = ssim_amd.compute_ssim(ha, hb)
         if args.mode == 0:
             assert int(hv.view(np.uint32)) == kats[0]
-        t1 = time.perf_counter()
-        for _ in range(5):
-            ssim_amd.compute_ssim(ha, hb)
-        dth = (time.perf_counter() - t1) / 5
-        # ... and with the per-pixel map copied back into a caller-owned pageable buffer
+        def best_and_median(fn, n):
+            fn()
+            ts = []
+            for _ in range(n):
+                t_ = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t_)
+            return min(ts), statistics.median(ts)
+        dth, dth_med = best_and_median(lambda: ssim_amd.compute_ssim(ha, hb), 6)
+        # ... and with the per-pixel map copied back into a caller-owned pageable buffer (banded pipeline)
         hmap = np.zeros((H, W), np.float32)
         hv2, _ = ssim_amd.compute_ssim(ha, hb, out_map=hmap)
         assert int(hv2.view(np.uint32)) == int(hv.view(np.uint32)) and abs(float(hmap.mean(dtype=np.float64)) - float(hv)) < 1e-6
-        t1 = time.perf_counter()
-        for _ in range(3):
-            ssim_amd.compute_ssim(ha, hb, out_map=hmap)
-        dthm = (time.perf_counter() - t1) / 3
+        dthm, dthm_med = best_and_median(lambda: ssim_amd.compute_ssim(ha, hb, out_map=hmap), 6)
         # a batch of host-resident pairs through the pipelined entry point (PCIe staging overlapped with the kernels)
         nb = max(2, min(8, (256 << 20) // (2 * W * H)))
         hp = [(ha, hb)] * nb
@@ -489,7 +491,10 @@ def main():
                   "host_batch_pairs": nb, "host_batch_ms_per_pair": round(dtb * 1e3, 3), "host_batch_mpix_s": round(W * H / dtb / 1e6, 1),
                   "blocking_call_ms": round(dts * 1e3, 4), "blocking_call_mpix_s": round(W * H / dts / 1e6, 1),
                   "host_pointer_call_ms": round(dth * 1e3, 3), "host_pointer_call_mpix_s": round(W * H / dth / 1e6, 1),
-                  "host_pointer_call_with_map_ms": round(dthm * 1e3, 3), "host_pointer_call_with_map_mpix_s": round(W * H / dthm / 1e6, 1)}
+                  "host_pointer_call_median_ms": round(dth_med * 1e3, 3),
+                  "host_pointer_call_with_map_ms": round(dthm * 1e3, 3), "host_pointer_call_with_map_mpix_s": round(W * H / dthm / 1e6, 1),
+                  "host_pointer_call_with_map_median_ms": round(dthm_med * 1e3, 3),
+                  "host_pointer_note": "unchanged rmgr_ssim_compute_ssim on pageable host memory, PCIe staging included; best and median of 6 calls"}
         del hmap, ha, hb
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)      # restore the slice for consistency
         torch.cuda.synchronize()

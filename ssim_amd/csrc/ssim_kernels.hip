@@ -908,31 +908,36 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     }
 }
 
-// Per-image sum of the cell partials in a fixed order (thread t takes partials t, t+256, ...; then a fixed LDS
-// tree), so the result depends on nothing but the image size.  Images with many cells (an 8192^2 pair has 131072)
-// are first cut into chunks of kReduceChunk cells, one block each (grid.y), then the chunk sums are summed the
-// same way: two short launches instead of one CU reading a megabyte.
+// Per-image sum of the cell partials in a fixed order, so that the result depends on nothing but the image size:
+// thread t of 1024 adds partials t, t+1024, ... in that order; each wave then runs a fixed xor butterfly (every lane
+// ends with the same bits); the 16 wave totals are added in wave order.  Images with many cells (an 8192^2 pair has
+// 32768) are first cut into chunks of kReduceChunk cells, one block each (grid.y), then the chunk sums are summed the
+// same way.  One 4096^2 image: 8192 cells = 8 loads per thread (a single 256-thread tree took 8.7 us of a 96 us launch).
 constexpr uint32_t kReduceChunk = 8192;
+constexpr int      kReduceThreads = 1024;
 
-__global__ __launch_bounds__(256) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, uint32_t chunk, double* __restrict__ sums)
+__global__ __launch_bounds__(kReduceThreads) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, uint32_t chunk, double* __restrict__ sums)
 {
-    __shared__ double sh[256];
+    __shared__ double sh[kReduceThreads / 64];
     const uint32_t first = blockIdx.y * chunk;
     const uint32_t n = per_image - first < chunk ? per_image - first : chunk;
     const double* p = partials + (size_t)blockIdx.x * per_image + first;
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256)
+    for (uint32_t i = threadIdx.x; i < n; i += kReduceThreads)
         acc += p[i];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
 #pragma unroll
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0)
+        sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+#pragma unroll
+        for (int w = 1; w < kReduceThreads / 64; ++w)
+            t += sh[w];
+        sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
     }
-    if (threadIdx.x == 0)
-        sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = sh[0];
 }
 
 template <int MODE, bool QREG = false>
@@ -1113,10 +1118,10 @@ hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hi
     if (per > kReduceChunk) {
         const uint32_t chunks = (per + kReduceChunk - 1) / kReduceChunk;
         double* chunk_sums = partials + (size_t)geo.count * per;
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(256), 0, stream, partials, per, kReduceChunk, chunk_sums);
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(256), 0, stream, chunk_sums, chunks, chunks, sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(kReduceThreads), 0, stream, partials, per, kReduceChunk, chunk_sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(kReduceThreads), 0, stream, chunk_sums, chunks, chunks, sums);
     } else {
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(256), 0, stream, partials, per, per, sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(kReduceThreads), 0, stream, partials, per, per, sums);
     }
     return hipGetLastError();
 }

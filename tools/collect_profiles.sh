@@ -11,12 +11,18 @@ for wl in 4k 8k-map 1080p; do
   grep '"metric"' "$OUT/bench_$wl.log" > "$OUT/bench_$wl.json"
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-configs > "$OUT/bench_rccl_1rank.log" 2>&1
+grep '"metric"' "$OUT/bench_rccl_1rank.log" > "$OUT/bench_rccl_1rank.json"
+SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-configs --workload 1080p --scaling strong > "$OUT/bench_c4_strong.log" 2>&1
+grep '"metric"' "$OUT/bench_c4_strong.log" > "$OUT/bench_c4_strong.json"
+timeout 300 python3 tools/host_call_probe.py 4096 1,8 > "$OUT/host_call_probe.txt" 2>&1
+timeout 300 python3 tools/latency_probe.py > "$OUT/latency_probe.txt" 2>&1
 grep '"metric"' "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json"
 pmc() {   # name, counters, target args...
   local name=$1 ctrs=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
 }
-for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096"; do
+for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
   set -- $cfg; tag=$1; shift
   pmc ${tag}_fetch FETCH_SIZE "$@"
   pmc ${tag}_write WRITE_SIZE "$@"
