@@ -204,6 +204,40 @@ __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V
     acc[10] = h * VT<V>::splat(g[5]);
 }
 
+// The same for two independent streams (the lane's two columns), their row passes interleaved: a stream's six
+// multiply-adds form one dependent chain, and back-to-back dependent packed instructions cost a wait state each on
+// gfx950 (the compiler pads them with s_nop) -- with two waves per SIMD there is nobody else to fill those slots.
+template <bool SMALL_FIRST = false, typename V, typename G>
+__device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11], const V (&a)[6], const V (&b)[6], const G (&g)[6])
+{
+    V hA, hB;
+    if constexpr (SMALL_FIRST) {
+        hA = a[5] * VT<V>::splat(g[5]);
+        hB = b[5] * VT<V>::splat(g[5]);
+#pragma unroll
+        for (int i = 4; i >= 0; --i) {
+            hA = fma_(a[i], VT<V>::splat(g[i]), hA);
+            hB = fma_(b[i], VT<V>::splat(g[i]), hB);
+        }
+    } else {
+        hA = a[0] * VT<V>::splat(g[0]);
+        hB = b[0] * VT<V>::splat(g[0]);
+#pragma unroll
+        for (int i = 1; i <= 5; ++i) {
+            hA = fma_(a[i], VT<V>::splat(g[i]), hA);
+            hB = fma_(b[i], VT<V>::splat(g[i]), hB);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const int t = k < 5 ? 5 - k : k - 5;
+        accA[k] = ring_fma(hA, g[t], accA[k + 1]);
+        accB[k] = ring_fma(hB, g[t], accB[k + 1]);
+    }
+    accA[10] = hA * VT<V>::splat(g[5]);
+    accB[10] = hB * VT<V>::splat(g[5]);
+}
+
 // Per-pixel SSIM, unfused fp32 exactly as src/ssim.cpp:681-693 / src/ssim_avx.cpp:342-352.
 // 2*x + c is written as fma(2,x,c): 2*x is exact, so the single rounding is the same one.
 __device__ __forceinline__ float ssim_px(float muA, float muB, float eAA, float eBB, float eAB, float c1, float c2)
@@ -621,10 +655,13 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if constexpr (EXACT) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
-            else                 blur_separable<true>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4], gf);
+            for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+        } else {
+            const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
+            const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
+            blur_separable_pair<true>(accAB[0], accAB[1], s0, s1, gf);
         }
         // (4) the (a*a,b*b) streams
         __builtin_amdgcn_sched_barrier(0);
@@ -632,13 +669,18 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
 #pragma unroll
             for (int k = 1; k <= 12; ++k) wq[k] = wab[k] * wab[k];
         }
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int m = 6 + c;
-            const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
-                     q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
-            if constexpr (EXACT) blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
-            else                 blur_separable(accQ[c], wq[m], q1, q2, q3, q4, q5, gf);
+            for (int c = 0; c < 2; ++c) {
+                const int m = 6 + c;
+                const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
+                         q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
+                blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
+            }
+        } else {
+            const f2 s0[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
+            const f2 s1[6] = {wq[7], wq[8] + wq[6], wq[9] + wq[5], wq[10] + wq[4], wq[11] + wq[3], wq[12] + wq[2]};
+            blur_separable_pair(accQ[0], accQ[1], s0, s1, gf);
         }
         if constexpr (!QREG) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
         else                 asm volatile("" :: "v"(wxx[0]));
