@@ -76,6 +76,10 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint3
  * back (any ssimStep/ssimStride), returns the global SSIM.  Validation and return codes are the
  * reference's (src/ssim.cpp:962-978).  ctx may be NULL: a process-wide default context on
  * device 0 (or $RMGR_SSIM_HIP_DEVICE) is used under a lock.
+ * A large pair with a map is processed in row bands -- copy-in of band k+1, kernel on band k and the copy-back of
+ * band k-1's map rows (by a short-lived helper thread, straight into ssimMap) overlap; the results are bit-identical
+ * to the one-launch computation.  $RMGR_SSIM_HIP_BANDS overrides the band count (1: no overlap).
+ * The calling thread's current HIP device is left as it was (true of every function in this header).
  */
 rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* ctx, float* ssim, const rmgr_ssim_Params* params,
                                              const rmgr_ssim_ThreadPool* threadPool) RMGR_NOEXCEPT;
@@ -89,8 +93,10 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* ctx, float
 /*
  * Asynchronous batch: `count` pairs of identical width/height, all pointers device-resident.
  * One launch covers the whole batch; image i's fp64 sum of per-pixel SSIM values is written to
- * sumsDevice[i] (device memory, count doubles) in a fixed reduction order, so the value does not
- * depend on how a batch is split across calls, contexts or GPUs.  Returns once enqueued.
+ * sumsDevice[i] (device memory, count doubles).  The reduction is organised in cells at fixed image positions and
+ * summed in a fixed order, so the value is bit-identical however a batch is split across calls, contexts or GPUs
+ * and whatever the tuning.  Different batches may be enqueued back to back: the descriptor tables are kept in a
+ * small ring, nothing waits for the stream.  Returns once enqueued.
  */
 rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
                                          double* sumsDevice) RMGR_NOEXCEPT;
