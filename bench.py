@@ -53,13 +53,14 @@ WORKLOADS = {
 NAIVE_F64_4K = 0.893428737869049      # tests/ssim_naive.h compute_ssim<double> on the 4096^2 seed-0x5EED pair
 HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # fp32 VALU work per output pixel: exact = 5 planes x (5 fold adds + 6 mul + 30 fma + 10 ring adds)
-# + 23 for the SSIM formula / divide / fp64 accumulate; separable = 5 x 22 + 23; fp64 mode = 108 fp64 ops
-VALU_OPS_PER_PIXEL = {0: 278, 1: 133, 2: 108, 3: 278}
+# + 23 for the SSIM formula / divide / fp64 accumulate; separable = 4 planes x 22 + 23 (a^2 + b^2 is blurred as one
+# plane); fp64 mode = 4 x 22 fp64 blur ops
+VALU_OPS_PER_PIXEL = {0: 278, 1: 111, 2: 88, 3: 278}
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
 VALU_MEASURED_2WAVE_TOPS = 58.1       # the same probe at the 2 waves/SIMD the kernel's 110 accumulator VGPRs allow
-MODE_NAMES = ["exact (reference FMA order, bit-faithful)", "fast (separable fp32)", "double (fp64 internals)", "unfused (reference AVX order)"]
+MODE_NAMES = ["exact (reference FMA order, bit-faithful)", "fast (separable fp32, four planes)", "double (fp64 internals)", "unfused (reference AVX order)"]
 
 
 # ------------------------------------------------------------------------------------------------

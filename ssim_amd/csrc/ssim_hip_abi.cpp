@@ -243,7 +243,10 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     int variant = c->variant;
     for (uint32_t i = 0; i < count && variant != 1; ++i)
         if (!ssim_hip::fits_strip2(descs[i], width, height)) variant = 1;
-    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
+    ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
+    geo.map_unit = any_map && (width & 1u) == 0;     // the 8-byte map stores of the two-column kernel (ssim_kernels.hip, MAP == 2)
+    for (uint32_t i = 0; i < count && geo.map_unit; ++i)
+        geo.map_unit = descs[i].map != NULL && descs[i].map_step == 1;
     int rc = grow_device(c->partials, c->partials_cap, ssim_hip::partials_size(geo));
     if (rc) return rc;
     PairDesc single = descs[0];

@@ -27,6 +27,7 @@ struct Geometry {
     uint32_t y_begin, y_end;      // output rows [y_begin, y_end) this launch produces; y_begin is a multiple of cell_rows
     uint32_t cell_rows;           // rows per reduction cell: cell_rows_for(height)
     uint32_t cells_x, cells_y;    // the image's 64-column x cell_rows-row reduction cells (ssim_kernels.hip, cell_flush*)
+    bool     map_unit;            // every pair of the launch writes its map with ssimStep == 1 (set by the caller of plan(); scheduling only)
     uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 

@@ -31,6 +31,11 @@
 #include <cmath>
 #include <type_traits>
 
+// Cache policy of the map stores: nt (non-temporal).  The map is written once and never read by the kernel; as ordinary
+// write-back lines it competes with the input rows for L2 and costs MODE_FAST 18 % with a map (8192^2: 333 -> 391 Gpix/s
+// with nt; MODE_EXACT +2.7 %; profiles/r02_map_store_ab.txt).
+#define SSIM_MAP_STORE_AUX 2
+
 namespace ssim_hip {
 namespace {
 
@@ -164,33 +169,30 @@ __device__ __forceinline__ d2 ring_fma(d2 h, double g, d2 c)
 // sums, then the vertical pass as the same ring scatter.  g[] = centre..edge taps of the true
 // 1-D Gaussian (g(x)g(y) equals the 2-D kernel of tests/ssim_naive.h to 7e-18).
 //
-// SMALL_FIRST: the row pass adds its terms from the outermost (smallest) tap inwards instead of centre first.
-// In fp32 the centre-first order -- the reference's own -- has a systematic rounding drift; through sigma^2 =
-// E[x^2] - mu^2 the mu planes carry almost all of it into the global value (einstein/jpg: -2.03e-6 against the
-// double oracle, the reference FMA path itself -1.55e-6).  MODE_FAST therefore sums its two mu streams small
-// taps first and keeps the E[.] streams centre first: on the 18 fixtures that is within 4.2e-7 of the exact value
-// (the reference's test tolerance is 2e-6) AND within 1.13e-6 of the FMA path (north_star's 1.5e-6); all five
-// streams small-first would be as accurate but 1.97e-6 from the FMA path on that image, all centre-first is the
-// 2.03e-6 above (tests/tools/fast_mode_model.py reproduces the numbers on the CPU).  Same instruction count.
-template <bool SMALL_FIRST = false, typename V, typename G>
+// ORDER: the order in which the row pass adds its six terms (tap index 0 = centre .. 5 = edge).  In fp32 the order
+// matters for the GLOBAL value: centre first -- the reference's own order -- rounds with a systematic drift, and
+// through sigma^2 = E[x^2] - mu^2 the mu planes carry almost all of it into the mean (einstein/jpg: -1.7e-6 against
+// the double oracle; the reference FMA path itself is -1.55e-6).  MODE_FAST answers to two tolerances that pull
+// apart on that image -- the reference's test tolerance against the exact value (2e-6) and north_star's against the
+// FMA path (1.5e-6) -- and uses the orders that sit between the two with the widest margins on the 18 fixtures
+// (tests/tools/fast_mode_model.py reproduces the kernel's arithmetic on the CPU and tabulates the candidates):
+//   mu streams     ORDER_INNER_FIRST   2,1,0,3,4,5
+//   E[.] streams   ORDER_SMALL_FIRST   5,4,3,2,1,0
+// -> worst global error 9.5e-7 vs the oracle, 6.0e-7 vs the FMA path.  Same instruction count for every order.
+enum { ORDER_CENTRE_FIRST = 0, ORDER_SMALL_FIRST = 1, ORDER_INNER_FIRST = 2 };
+template <int ORDER> __device__ constexpr int tap_at(int k)
+{
+    return ORDER == ORDER_CENTRE_FIRST ? k : ORDER == ORDER_SMALL_FIRST ? 5 - k : (k < 3 ? 2 - k : k);
+}
+
+template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
 __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5, const G (&g)[6])
 {
-    V h;
-    if constexpr (SMALL_FIRST) {
-        h = s5 * VT<V>::splat(g[5]);
-        h = fma_(s4, VT<V>::splat(g[4]), h);
-        h = fma_(s3, VT<V>::splat(g[3]), h);
-        h = fma_(s2, VT<V>::splat(g[2]), h);
-        h = fma_(s1, VT<V>::splat(g[1]), h);
-        h = fma_(s0, VT<V>::splat(g[0]), h);
-    } else {
-        h = s0 * VT<V>::splat(g[0]);
-        h = fma_(s1, VT<V>::splat(g[1]), h);
-        h = fma_(s2, VT<V>::splat(g[2]), h);
-        h = fma_(s3, VT<V>::splat(g[3]), h);
-        h = fma_(s4, VT<V>::splat(g[4]), h);
-        h = fma_(s5, VT<V>::splat(g[5]), h);
-    }
+    const V s[6] = {s0, s1, s2, s3, s4, s5};
+    V h = s[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
+#pragma unroll
+    for (int k = 1; k < 6; ++k)
+        h = fma_(s[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), h);
     acc[0] = ring_fma(h, g[5], acc[1]);
     acc[1] = ring_fma(h, g[4], acc[2]);
     acc[2] = ring_fma(h, g[3], acc[3]);
@@ -207,26 +209,15 @@ __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V
 // The same for two independent streams (the lane's two columns), their row passes interleaved: a stream's six
 // multiply-adds form one dependent chain, and back-to-back dependent packed instructions cost a wait state each on
 // gfx950 (the compiler pads them with s_nop) -- with two waves per SIMD there is nobody else to fill those slots.
-template <bool SMALL_FIRST = false, typename V, typename G>
+template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
 __device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11], const V (&a)[6], const V (&b)[6], const G (&g)[6])
 {
-    V hA, hB;
-    if constexpr (SMALL_FIRST) {
-        hA = a[5] * VT<V>::splat(g[5]);
-        hB = b[5] * VT<V>::splat(g[5]);
+    V hA = a[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
+    V hB = b[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
 #pragma unroll
-        for (int i = 4; i >= 0; --i) {
-            hA = fma_(a[i], VT<V>::splat(g[i]), hA);
-            hB = fma_(b[i], VT<V>::splat(g[i]), hB);
-        }
-    } else {
-        hA = a[0] * VT<V>::splat(g[0]);
-        hB = b[0] * VT<V>::splat(g[0]);
-#pragma unroll
-        for (int i = 1; i <= 5; ++i) {
-            hA = fma_(a[i], VT<V>::splat(g[i]), hA);
-            hB = fma_(b[i], VT<V>::splat(g[i]), hB);
-        }
+    for (int k = 1; k < 6; ++k) {
+        hA = fma_(a[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), hA);
+        hB = fma_(b[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), hB);
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
@@ -307,6 +298,36 @@ __device__ __forceinline__ f2 ssim_px2_tail(const Px2& h, f2 eAB, float c1, floa
     const f2 sAB = eAB - h.muAB;
     const f2 n = fma_(two, h.muAB, C1) * fma_(two, sAB, C2);
     return div_inrange_finish(n, h.den, h.rcp);
+}
+
+// MODE_FAST works on FOUR blurred planes, not five: the SSIM formula needs the two variances only as their sum,
+// sigma_a^2 + sigma_b^2 = E[a^2 + b^2] - (mu_a^2 + mu_b^2), so a^2 + b^2 (an exact integer <= 130050 in fp32) is
+// blurred as one plane.  A fifth of the blur work, of the accumulator registers and of the staged LDS bytes goes away,
+// and the ab plane can share a float2 with it -- (a^2 + b^2, ab) per pixel -- which packs like the (a, b) plane does.
+// One pixel, scalar form (the one-column kernel); the packed form below performs the same operations on both columns
+// of a lane, so the two kernels agree bit for bit.
+template <typename T>
+__device__ __forceinline__ T ssim_px_fast(T muA, T muB, T eS, T eX, T c1, T c2)
+{
+    const T muAB = muA * muB;
+    const T tm = muA * muA + muB * muB;            // mul, mul, add: three roundings (-ffp-contract=off)
+    const T ts = eS - tm, sAB = eX - muAB;
+    const T num = fma_(T(2), muAB, c1) * fma_(T(2), sAB, c2);     // 2x is exact: the one rounding of 2x + c
+    const T den = (tm + c1) * (ts + c2);
+    return num / den;
+}
+// mu0, mu1 = (mu_a, mu_b) of the lane's two columns; e0, e1 = (E[a^2+b^2], E[ab]) of the two columns
+__device__ __forceinline__ f2 ssim_px2_fast(f2 mu0, f2 mu1, f2 e0, f2 e1, float c1, float c2)
+{
+    const f2 m0 = mu0 * mu0, m1 = mu1 * mu1;
+    const f2 muAB = {opaque(mu0.x * mu0.y), opaque(mu1.x * mu1.y)};
+    const f2 tm = {opaque(m0.x + m0.y), opaque(m1.x + m1.y)};
+    const f2 ts = {opaque(e0.x - tm.x), opaque(e1.x - tm.y)};
+    const f2 sAB = {opaque(e0.y - muAB.x), opaque(e1.y - muAB.y)};
+    const f2 two = {2.0f, 2.0f}, C1 = {c1, c1}, C2 = {c2, c2};
+    const f2 n = fma_(two, muAB, C1) * fma_(two, sAB, C2);
+    const f2 den = (tm + C1) * (ts + C2);
+    return div_inrange_finish(n, den, div_inrange_rcp(den));      // operand ranges as for ssim_px2_head/tail
 }
 
 struct KArgs {
@@ -471,19 +492,22 @@ struct Slot2 {
 
 enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 
-// QREG (MODE_FAST): the (a*a, b*b) plane is not staged in LDS; the products are formed in registers from the (a,b)
-// window (+12 packed multiplies, -7 of 20 window reads per lane-row).  Round-2 experiment on the separable mode's LDS
-// co-limit (profiles/r02_fast_lds_attack.md): LDS issue stalls 39 M -> 12 M per launch, VALU-busy 72 -> 77 %, +3.3...4.4 %;
-// bit-identical results.  Storing the ab plane once and running its two columns as scalar streams was also measured
-// (alone -1...-5 %, together with this +2...3 %) and dropped.  Tuning variant 2 selects the round-1 layout (QREG off).
-template <int MODE, bool MAP, bool QREG = false>
-__global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
+// MODE_FAST (round 2): four planes -- the (a,b) pair plane and the (a^2 + b^2, ab) pair plane (ssim_px_fast above),
+// both float2 per pixel, so the lane's four packed streams are (a,b) and (a^2+b^2, ab) of each of its two columns;
+// the `q` member of the slot holds the second plane, `xx` is not used.  14 window reads per lane-row (round 1: 20).
+// Measured before that, on the five-plane form (profiles/r02_fast_lds_attack.md, r02_fast_interleave_ab.txt):
+// products formed in registers instead of staged +3.3...4.4 %, interleaved row passes +1.4 %.
+// MAP: 0 no map; 1 map with any ssimStep (one 4-byte store per column); 2 every pair of the launch has ssimStep == 1
+// and the width is even (no lane owns a lone last column): the lane's two adjacent values go out as one 8-byte store
+// (a wave writes 512 contiguous bytes per row; +2...3 % for MODE_FAST with a map, neutral for MODE_EXACT).
+template <int MODE, int MAP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_FAST ? 3 : 2, MODE == MODE_FAST ? 3 : 2)))
+void ssim_strip2_kernel(const KArgs args)
 {
-    static_assert(!QREG || MODE == MODE_FAST, "the register-product layout exists for MODE_FAST only");
+    constexpr bool FAST = (MODE == MODE_FAST);
     constexpr int PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
     constexpr int NLOAD = 3;                         // pixels each lane stages per row
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
-    constexpr bool EXACT = (MODE == MODE_EXACT || MODE == MODE_UNFUSED);
     static_assert(MODE != MODE_DOUBLE, "fp64 mode uses ssim_strip1_kernel");
 
     __shared__ __attribute__((aligned(16))) Slot2 ring[2];
@@ -545,9 +569,13 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             const float x = a * b;                            // multiply (exact for 8-bit inputs)
             const int p = sp[t];
             s.ab[p] = ab;
-            if constexpr (!QREG) s.q[p] = ab * ab;
-            xf[2 * p] = x;                          // xx[p].lo
-            xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
+            if constexpr (FAST) {
+                s.q[p] = f2{__builtin_fmaf(b, b, a * a), x};      // (a^2 + b^2, ab): exact integers
+            } else {
+                s.q[p] = ab * ab;
+                xf[2 * p] = x;                          // xx[p].lo
+                xf[p > 0 ? 2 * p - 1 : 0] = x;          // xx[p-1].hi (p == 0: rewrites xx[0].lo with the same value)
+            }
         }
     };
     auto stage = [&](Slot2& s) { stage_from(s, va, vb); };
@@ -581,7 +609,7 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
     for (int c = 0; c < 2; ++c) {
         const int x = x0 + 2 * lane + c;
         col_ok[c] = x < W;
-        if constexpr (MAP) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0x80000000u;
+        if constexpr (MAP != 0) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0x80000000u;
     }
 
     // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
@@ -641,35 +669,31 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
         // Whole 16-byte reads only: 8-byte reads at this 16-byte lane stride are 2-way bank conflicts.  The three
         // end entries the wide form loads without need are kept alive until their planes are consumed (see load_ab).
-        if constexpr (!QREG) {
 #pragma unroll
-            for (int t = 0; t < 7; ++t) {
-                const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
-                wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
-            }
+        for (int t = 0; t < 7; ++t) {
+            const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
+            wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
         }
+        if constexpr (!FAST) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
-            wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+            for (int t = 0; t < 6; ++t) {
+                const f4 z = *reinterpret_cast<const f4*>(&s.xx[e + 2 * t]);
+                wxx[2 * t] = z.xy; wxx[2 * t + 1] = z.zw;
+            }
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (EXACT) {
+        if constexpr (!FAST) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
         } else {
             const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
             const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
-            blur_separable_pair<true>(accAB[0], accAB[1], s0, s1, gf);
+            blur_separable_pair<ORDER_INNER_FIRST>(accAB[0], accAB[1], s0, s1, gf);
         }
-        // (4) the (a*a,b*b) streams
+        // (4) the (a*a,b*b) streams / MODE_FAST: the (a*a + b*b, ab) streams
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (QREG) {                           // (a*a, b*b) of the window pixels, in registers
-#pragma unroll
-            for (int k = 1; k <= 12; ++k) wq[k] = wab[k] * wab[k];
-        }
-        if constexpr (EXACT) {
+        if constexpr (!FAST) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int m = 6 + c;
@@ -677,26 +701,26 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
                          q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
                 blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
             }
+            asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
         } else {
             const f2 s0[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
             const f2 s1[6] = {wq[7], wq[8] + wq[6], wq[9] + wq[5], wq[10] + wq[4], wq[11] + wq[3], wq[12] + wq[2]};
-            blur_separable_pair(accQ[0], accQ[1], s0, s1, gf);
+            blur_separable_pair<ORDER_SMALL_FIRST>(accQ[0], accQ[1], s0, s1, gf);
+            asm volatile("" :: "v"(wq[0]), "v"(wq[13]));
         }
-        if constexpr (!QREG) asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
-        else                 asm volatile("" :: "v"(wxx[0]));
-        // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
-        //     with more than 15 LDS operations in flight the compiler can only drain them all.
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
-        // (6) the ab stream
-        __builtin_amdgcn_sched_barrier(0);
         Px2 head;
-        if constexpr (phase != ROW_WARMUP)
-            head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
-        {   // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
+        if constexpr (!FAST) {
+            // (5) request the NEXT row's (a,b) window (the other slot was staged an iteration ago).  Not earlier:
+            //     with more than 15 LDS operations in flight the compiler can only drain them all.
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
+            // (6) the ab stream
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (phase != ROW_WARMUP)
+                head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
+            // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
-            if constexpr (EXACT) blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
-            else                 blur_separable(accX, wxx[6], x1, x2, x3, x4, x5, gf);
+            blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -707,22 +731,30 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
         // the image are computed like any other, dropped from the sum at the end and given an out-of-range
         // map offset up front.
         if constexpr (phase != ROW_WARMUP) {
-            const f2 v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
+            f2 v;
+            if constexpr (FAST) v = ssim_px2_fast(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
+            else                v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
             colsum[0] += (double)v.x;               // fp64 accumulation, src/ssim_avx.cpp:357-358
             colsum[1] += (double)v.y;
-            if constexpr (MAP) {
+            if constexpr (MAP != 0) {
                 // Branch-free store: a raw buffer descriptor over [row base, +2 GiB); lanes with nothing to
                 // store present an offset beyond it and the hardware drops the write.
                 const int y = r - 5;
                 float* mrow = pd.map + ((int64_t)y * pd.map_stride + (int64_t)refM * pd.map_step);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mrow, 0, 0x7FFFFFFF, 0x00020000);
                 const float v0 = v.x, v1 = v.y;     // (bit_cast straight from a vector element reads element 0 for both)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), rs, offM[0], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), rs, offM[1], 0, 0);
+                if constexpr (MAP == 2) {
+                    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                    const u2 both = {__builtin_bit_cast(uint32_t, v0), __builtin_bit_cast(uint32_t, v1)};
+                    __builtin_amdgcn_raw_buffer_store_b64(both, rs, offM[0], 0, SSIM_MAP_STORE_AUX);     // even width: both columns or neither
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v0), rs, offM[0], 0, SSIM_MAP_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v1), rs, offM[1], 0, SSIM_MAP_STORE_AUX);
+                }
             }
         }
         __builtin_amdgcn_s_setprio(0);
-        if constexpr (phase != ROW_LAST) {
+        if constexpr (phase != ROW_LAST && !FAST) {
             __builtin_amdgcn_sched_barrier(0);
             fold_ab();                                  // row r+1 (window requested in step (5))
             __builtin_amdgcn_sched_barrier(0);
@@ -730,6 +762,20 @@ __global__ __launch_bounds__(64) void ssim_strip2_kernel(const KArgs args)
             stage(ring[cur]);                           // row r+2 replaces row r
             fetch(r + 3);
             wave_sync();
+        }
+        if constexpr (phase != ROW_LAST && FAST) {
+            // MODE_FAST runs three waves per SIMD (168 VGPRs): the next row's (a,b) window is requested only now, so
+            // that its 28 registers are not live during the streams above, and folded behind the staging of row r+2
+            // (the other two waves cover the latency).
+            __builtin_amdgcn_sched_barrier(0);
+            load_ab(ring[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            wave_sync();
+            stage(ring[cur]);                           // row r+2 replaces row r
+            fetch(r + 3);
+            wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            fold_ab();                                  // row r+1
         }
     };
     typedef std::integral_constant<int, 0> S0;
@@ -781,6 +827,8 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     constexpr int PAD = Slot1::PAD, ROW_PX = Slot1::ROW_PX;
     constexpr int NLOAD = 2;
     constexpr bool DBL = (MODE == MODE_DOUBLE);
+    constexpr bool FAST = (MODE == MODE_FAST);
+    constexpr bool FOUR = FAST || DBL;               // four planes: (a,b) and (a*a + b*b, ab), see ssim_px_fast
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
     typedef typename std::conditional<DBL, d2, f2>::type PV;         // plane-pair streams
     typedef typename std::conditional<DBL, double, float>::type XV;  // ab stream
@@ -823,8 +871,12 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
             const float a = (float)ia[t], b = (float)ib[t];
             const f2 ab = {a, b};
             s.ab[sp[t]] = ab;
-            s.q[sp[t]] = ab * ab;
-            s.x[sp[t]] = a * b;
+            if constexpr (FOUR) {
+                s.q[sp[t]] = f2{__builtin_fmaf(b, b, a * a), a * b};
+            } else {
+                s.q[sp[t]] = ab * ab;
+                s.x[sp[t]] = a * b;
+            }
         }
     };
     auto stage = [&](Slot1& s) { stage_from(s, va, vb); };
@@ -873,7 +925,8 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
 
     auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream) {
         if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
-        else if constexpr (MODE == MODE_FAST)                     blur_separable<decltype(mu_stream)::value>(acc, s0, s1, s2, s3, s4, s5, args.gf);
+        else if constexpr (FAST)   // the same tap orders as the two-column kernel: the two agree bit for bit
+            blur_separable<decltype(mu_stream)::value ? ORDER_INNER_FIRST : ORDER_SMALL_FIRST>(acc, s0, s1, s2, s3, s4, s5, args.gf);
         else  // fp64 internals: the folded sums are exact integers in fp32; everything after is double
             blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
     };
@@ -887,7 +940,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
             wq[t] = s.q[base + t];
-            wx[t] = s.x[base + t];
+            if constexpr (!FOUR) wx[t] = s.x[base + t];
         }
         __builtin_amdgcn_sched_barrier(0);
         blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4], std::true_type());
@@ -896,22 +949,27 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
-        blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type());
+        if constexpr (!FOUR)
+            blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type());
         __builtin_amdgcn_sched_barrier(0);
 
         if constexpr (phase != ROW_WARMUP) {         // ring entry 0 is the finished output row y = r - 5
             float vmap;
             if constexpr (DBL) {
-                const double v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1d, args.c2d);
+                const double v = ssim_px_fast(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1d, args.c2d);
                 colsum += v;
                 vmap = (float)v;                    // the reference's map is float in the double build too
+            } else if constexpr (FAST) {
+                const float v = ssim_px_fast(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1, args.c2);
+                colsum += (double)v;
+                vmap = v;
             } else {
                 const float v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1, args.c2);
                 colsum += (double)v;
                 vmap = v;
             }
             if constexpr (MAP) {
-                if (col_ok) ((gptr_f32)pd.map)[(r - 5) * pd.map_stride + map_off] = vmap;
+                if (col_ok) __builtin_nontemporal_store(vmap, &((gptr_f32)pd.map)[(r - 5) * pd.map_stride + map_off]);   // see SSIM_MAP_STORE_AUX
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -982,12 +1040,13 @@ __global__ __launch_bounds__(kReduceThreads) void ssim_reduce_kernel(const doubl
     }
 }
 
-template <int MODE, bool QREG = false>
+template <int MODE>
 hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
-    if (map) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, true, QREG>), grid, block, 0, stream, ka);
-    else     hipLaunchKernelGGL((ssim_strip2_kernel<MODE, false, QREG>), grid, block, 0, stream, ka);
+    if (!map)              hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0>), grid, block, 0, stream, ka);
+    else if (geo.map_unit) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 2>), grid, block, 0, stream, ka);
+    else                   hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 1>), grid, block, 0, stream, ka);
     return hipGetLastError();
 }
 
@@ -1103,6 +1162,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
 {
     Geometry g;
     g.width = width; g.height = height; g.count = count;
+    g.map_unit = false;
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     g.cell_rows = cell_rows_for(height);
@@ -1211,9 +1271,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     switch (mode) {
     case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
     case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
-    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)
-                           : variant == 2 ? launch_strip2<MODE_FAST, false>(geo, ka, map, stream)    // the round-1 LDS layout
-                                          : launch_strip2<MODE_FAST, true>(geo, ka, map, stream);    break;
+    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
     case MODE_DOUBLE:  err = launch_strip1<MODE_DOUBLE>(geo, ka, map, stream); break;
     default:           return hipErrorInvalidValue;
     }

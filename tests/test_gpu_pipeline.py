@@ -222,9 +222,10 @@ def test_fast_mode_meets_the_reference_test_tolerances(gpu_ctx, manifest):
     finally:
         gpu_ctx.set_tuning(0, 0)
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
-    # the CPU model of the kernel's arithmetic (tests/tools/fast_mode_model.py) predicts 4.2e-7 / 1.13e-6 / 1.9e-4
-    assert worst_g < 6e-7, worst_g
-    assert worst_gf < 1.3e-6, worst_gf
+    # the CPU model of the kernel's arithmetic (tests/tools/fast_mode_model.py) predicts 9.5e-7 / 6.0e-7 / 2.3e-4:
+    # half the reference's test tolerance (2e-6) and 40 % of north_star's FMA-relative one (1.5e-6)
+    assert worst_g < 1.1e-6, worst_g
+    assert worst_gf < 8e-7, worst_gf
     assert worst_p < 3e-4, worst_p
 
 
@@ -256,14 +257,14 @@ def test_select_impl_switches_the_arithmetic_of_the_dropin_call(manifest):
         fn(AUTO)
 
 
-def test_fast_mode_lds_layouts_are_bit_identical(gpu_ctx, oracle):
-    """MODE_FAST forms (a*a, b*b) in registers by default (round 2); tuning variant 2 is the round-1 layout that stages
-    the plane in LDS, variant 1 the one-column kernel.  Same operations on the same values: identical bits."""
+def test_fast_mode_kernels_are_bit_identical(gpu_ctx, oracle):
+    """MODE_FAST's two kernels (two columns per lane / one column per lane, tuning variant 1) perform the same operations
+    in the same order on four blurred planes: identical bits."""
     a, b = oracle.synth_pair(700, 300, 0x5EED + 9)
     gpu_ctx.set_mode(ssim_amd.MODE_FAST)
     try:
         ref = None
-        for variant in (0, 2, 1):
+        for variant in (0, 1):
             gpu_ctx.set_tuning(0, variant)
             v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
             if ref is None:
