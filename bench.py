@@ -203,8 +203,11 @@ def attainable_hbm_gbs(torch, dev):
 
 
 def kernel_name(mode, variant, want_map):
-    one = mode == 2 or variant == 1
-    return "ssim_strip%d_kernel<%d,%s>" % (1 if one else 2, mode, "true" if want_map else "false")
+    """Template instance rocprofv3 lists for this configuration (ssim_kernels.hip): the two-column kernel's second argument
+    is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even); the one-column kernel's is a bool."""
+    if mode == 2 or variant == 1:
+        return "ssim_strip1_kernel<%d, %s>" % (mode, "true" if want_map else "false")
+    return "ssim_strip2_kernel<%d, %d>" % (mode, 2 if want_map else 0)
 
 
 def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
