@@ -811,8 +811,11 @@ void ssim_strip2_kernel(const KArgs args)
 //  * MODE_DOUBLE: the only shape whose fp64 accumulator rings (110 VGPRs) fit in the register file;
 //  * the fully general fallback of the fp32 modes: 64-bit coordinates and per-lane 64-bit offsets
 //    (image pairs fits_strip2() rejects) and tuning variant 1.  In fp32 it has half the accumulator
-//    registers of the two-column kernel but twice the loader/LDS work per pixel: 10-14 % slower.
-// The ab plane is a scalar stream here.
+//    registers of the two-column kernel but twice the loader/LDS work per pixel: 10-14 % slower
+//    (MODE_FAST: 25 % slower, although it runs four waves per SIMD there).
+// MODE_EXACT / MODE_UNFUSED: five planes, the ab plane a scalar stream.  MODE_FAST / MODE_DOUBLE: the four planes
+// of ssim_px_fast -- (a,b) and (a*a + b*b, ab) -- as two packed streams; MODE_DOUBLE then needs 160 VGPRs and runs
+// three waves per SIMD (five planes: 193 VGPRs, two waves; 8 x 4096^2 163 -> 214 Gpix/s).
 // ---------------------------------------------------------------------------------------------
 struct Slot1 {
     static constexpr int STRIP_W = 64, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;

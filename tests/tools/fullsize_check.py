@@ -2,7 +2,8 @@
 python tests/tools/fullsize_check.py [pairs=6] [size=4096]).  The pytest suite checks full-size runs through
 known answers, properties and a 512x512 corner + all four borders; this tool compares EVERY pixel of every map,
 in both bit-exact modes, plus the tolerance modes against the same oracle maps.
-Last run (final round-1 kernels): 6 x 4096^2 and 2 x 8192^2, 0 differing pixels in exact / unfused."""
+Last run (final round-2 kernels): 6 x 4096^2 and 2 x 8192^2, 0 differing pixels in exact / unfused;
+fast mode within 1.1e-7 (global) / 9.5e-5 (per pixel) of the FMA-order maps."""
 import os
 import sys
 

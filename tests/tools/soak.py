@@ -1,6 +1,6 @@
 """Randomized soak of the GPU path against the oracle: random sizes / layouts / modes / kernel variants / strip
-heights (run on the GPU box: python tests/tools/soak.py [cases=300] [seed=777]).  Last run (5000 cases, seed 2024,
-final round-1 kernels): 0 failures."""
+heights (run on the GPU box: python tests/tools/soak.py [cases=300] [seed=777]).  Last run (5000 cases, seed 2025,
+final round-2 kernels: cell reduction, four-plane fast / double modes, nt map stores): 0 failures."""
 import sys, numpy as np, ctypes
 import os; ROOT=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 import ssim_amd, oracle
