@@ -55,8 +55,9 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mode) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
 
-/* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the
- * kernel variant.  Results do not depend on either (tests/test_gpu_parity.py checks). */
+/* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the kernel variant
+ * (1: one column per lane, 2: two columns per lane; the default picks by launch size).  Results do not depend on
+ * either (tests/test_gpu_parity.py, tests/test_gpu_pipeline.py check). */
 rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT;
 
 /* How a launch of `count` width x height pairs is cut into wavefront strips under the context's mode and
@@ -64,7 +65,7 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t s
  * is touched.  The reference's counterpart is its 256x64 tile grid (src/ssim.cpp:1026-1028). */
 typedef struct rmgr_ssim_hip_Plan
 {
-    rmgr_uint32_t stripWidth;        /* output columns per wavefront: 128 (two per lane) or 64 */
+    rmgr_uint32_t stripWidth;        /* output columns per wavefront: 128 (two per lane) or 64 (one per lane: fp64 mode, tiny launches, tuning variant 1) */
     rmgr_uint32_t stripRows;         /* output rows per wavefront */
     rmgr_uint32_t stripsX, stripsY;  /* strips per image */
     rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count = workgroups of the launch */

@@ -241,6 +241,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
             uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu, bool reduce = true)
 {
     int variant = c->variant;
+    if (variant == 0 && c->strip_rows == 0) variant = ssim_hip::default_variant(width, height, count, c->mode, c->cu_count);
     for (uint32_t i = 0; i < count && variant != 1; ++i)
         if (!ssim_hip::fits_strip2(descs[i], width, height)) variant = 1;
     ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
@@ -620,8 +621,10 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t str
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT
 {
     if (!plan) return EINVAL;
-    const ssim_hip::Geometry geo = c ? ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count)
-                                     : ssim_hip::plan(width, height, count, RMGR_SSIM_HIP_MODE_EXACT, 0, 0, 256);
+    const int mode = c ? c->mode : RMGR_SSIM_HIP_MODE_EXACT, cus = c ? c->cu_count : 256, rows = c ? c->strip_rows : 0;
+    int variant = c ? c->variant : 0;
+    if (variant == 0 && rows == 0) variant = ssim_hip::default_variant(width, height, count, mode, cus);    // as enqueue() does
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, mode, rows, variant, cus);
     plan->stripWidth = geo.strip_w;
     plan->stripRows = geo.strip_rows;
     plan->stripsX = geo.strips_x;

@@ -62,6 +62,17 @@ inline int interleaved_group(const PairDesc* d, uint32_t count)
 }
 
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
+// The library default (tuning variant 0) is the two-column kernel, except for launches too small to give even a
+// quarter of the SIMDs a strip at the minimum strip height: there the one-column kernel's twice-as-many, half-as-wide
+// strips finish sooner (one 256^2 or 512^2 pair, bit-exact modes: 19.3 -> 15.4 us; equal from 1024^2 on; MODE_FAST
+// gains nothing).  Results do not depend on the choice (the cell reduction is common to both kernels).
+inline int default_variant(uint32_t width, uint32_t height, uint32_t count, int mode, int cu_count)
+{
+    if (mode != MODE_EXACT && mode != MODE_UNFUSED) return 0;
+    const uint64_t strips = (uint64_t)((width + 127) / 128) * ((height + 7) / 8) * count;
+    return strips * 4 <= (uint64_t)(cu_count > 0 ? cu_count : 256) * 4 ? 1 : 0;
+}
+
 // Rows per cell of the fp64 reduction: a function of the image height ONLY, so that every launch that touches an
 // image of this size -- any strip height, batch, band or GPU -- builds the same cells.  Images below 2048 rows keep
 // 8-row cells: a lone small image is cut into 8-row strips to fill the GPU, and 1080 rows split into five even

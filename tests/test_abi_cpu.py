@@ -234,13 +234,15 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     for (w, h, n) in [(1, 1, 1), (7, 3, 1), (128, 64, 1), (129, 65, 2), (256, 256, 1), (1920, 1080, 128), (4096, 4096, 1),
                       (4096, 4096, 32), (8192, 8192, 2), (65537, 3, 1), (3, 65537, 1), (255, 63, 1000)]:
         p = ssim_amd.get_plan(w, h, n)
-        assert p.stripWidth == 128 and p.stripRows >= 1
+        assert p.stripWidth in (64, 128) and p.stripRows >= 1
         assert (p.stripsX - 1) * p.stripWidth < w <= p.stripsX * p.stripWidth
         assert (p.stripsY - 1) * p.stripRows < h <= p.stripsY * p.stripRows
         assert p.wavefronts == p.stripsX * p.stripsY * n
     assert ssim_amd.get_plan(1920, 1080, 128).stripRows == 216          # 5 even strips, not 4 x 256 + 56
     assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 512           # >= 32 strips per CU left
     assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # a single image still gets 8 waves per CU
+    assert ssim_amd.get_plan(256, 256, 1).stripWidth == 64              # tiny launches: twice as many, half as wide strips
+    assert ssim_amd.get_plan(1024, 1024, 1).stripWidth == 128 and ssim_amd.get_plan(256, 256, 64).stripWidth == 128
     assert ssim_amd.get_plan(0, 0, 1).wavefronts == 0
     lib = ssim_amd.load_library()
     assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL

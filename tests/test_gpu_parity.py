@@ -33,7 +33,7 @@ def test_extension_is_loaded_and_device_is_gfx950(gpu_ctx):
     assert "gfx950" in d, d
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])      # library default (picks by launch size), one column per lane, two columns per lane
 def test_golden_fixtures_exact_mode(gpu_ctx, manifest, variant):
     gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
     gpu_ctx.set_tuning(0, variant)
@@ -81,7 +81,7 @@ SIZES = [(1, 1), (1, 37), (37, 1), (3, 200), (200, 3), (10, 10), (11, 11), (63, 
          (129, 128), (127, 129), (130, 600), (300, 301)]
 
 
-@pytest.mark.parametrize("variant,strip_rows", [(0, 0), (0, 7), (0, 64), (0, 5), (1, 0), (1, 33)])
+@pytest.mark.parametrize("variant,strip_rows", [(0, 0), (2, 0), (0, 7), (0, 64), (2, 5), (1, 0), (1, 33)])
 def test_random_and_ragged_sizes_vs_oracle(gpu_ctx, oracle, variant, strip_rows):
     gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
     gpu_ctx.set_tuning(strip_rows, variant)

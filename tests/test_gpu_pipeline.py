@@ -102,8 +102,8 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
         gpu_ctx.set_tuning(0, 0)
         ref = batch_sums(gpu_ctx, pairs, keep)
         assert np.all(np.isfinite(ref))
-        for strip_rows, variant, split in ((8, 0, None), (24, 0, None), (64, 1, None), (216, 0, None), (512, 1, None),
-                                           (0, 1, None), (0, 0, [(0, 1), (1, 4), (4, 6)]), (40, 0, [(0, 5), (5, 6)])):
+        for strip_rows, variant, split in ((8, 2, None), (24, 0, None), (64, 1, None), (216, 2, None), (512, 1, None),
+                                           (0, 1, None), (0, 2, None), (0, 0, [(0, 1), (1, 4), (4, 6)]), (40, 0, [(0, 5), (5, 6)])):
             gpu_ctx.set_tuning(strip_rows, variant)
             got = batch_sums(gpu_ctx, pairs, keep, split)
             assert np.array_equal(bits64(got), bits64(ref)), (mode, strip_rows, variant, split, got - ref)
@@ -204,7 +204,7 @@ def test_fast_mode_meets_the_reference_test_tolerances(gpu_ctx, manifest):
     gpu_ctx.set_mode(ssim_amd.MODE_FAST)
     worst_g = worst_p = worst_gf = 0.0
     try:
-        for variant in (0, 1):
+        for variant in (2, 1):
             gpu_ctx.set_tuning(0, variant)
             for name in image_entries(manifest):
                 ent = manifest[name]
@@ -264,7 +264,7 @@ def test_fast_mode_kernels_are_bit_identical(gpu_ctx, oracle):
     gpu_ctx.set_mode(ssim_amd.MODE_FAST)
     try:
         ref = None
-        for variant in (0, 1):
+        for variant in (2, 1, 0):
             gpu_ctx.set_tuning(0, variant)
             v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
             if ref is None:
