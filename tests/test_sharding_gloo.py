@@ -95,7 +95,9 @@ def test_bench_two_ranks_fail_only_at_the_missing_device():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
-    assert r.stderr.count("no HIP device visible") == 2, r.stderr[-1500:]
+    # every rank that gets to run says so; torchrun may terminate the slower one as soon as the first has failed
+    assert 1 <= r.stderr.count("no HIP device visible") <= 2, r.stderr[-1500:]
+    assert "starting 2 ranks" in r.stderr and "WORLD_SIZE" not in r.stderr
     assert "metric" not in r.stdout
 
 
