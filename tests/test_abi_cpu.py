@@ -243,6 +243,11 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # a single image still gets 8 waves per CU
     assert ssim_amd.get_plan(256, 256, 1).stripWidth == 64              # tiny launches: twice as many, half as wide strips
     assert ssim_amd.get_plan(1024, 1024, 1).stripWidth == 128 and ssim_amd.get_plan(256, 256, 64).stripWidth == 128
+    # strips start on the boundaries of the fp64 reduction cells: 32 rows for images of >= 2048 rows, else 8
+    for (w, h, n) in [(4096, 4096, 1), (4096, 4096, 32), (8192, 8192, 2), (5000, 2050, 3), (300, 2048, 1)]:
+        assert ssim_amd.get_plan(w, h, n).stripRows % 32 == 0, (w, h, n)
+    for (w, h, n) in [(1920, 1080, 1), (1920, 1080, 1024), (640, 480, 7), (300, 2047, 2), (129, 65, 2)]:
+        assert ssim_amd.get_plan(w, h, n).stripRows % 8 == 0, (w, h, n)
     assert ssim_amd.get_plan(0, 0, 1).wavefronts == 0
     lib = ssim_amd.load_library()
     assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL
