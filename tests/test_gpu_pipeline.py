@@ -185,6 +185,11 @@ def test_banded_host_call_equals_device_path(gpu_ctx, oracle, w, h):
     v2 = host_call(af, bf, 1, -w, af.ctypes.data + (h - 1) * w, 1, -w, bf.ctypes.data + (h - 1) * w, w, h, inter.ctypes.data, 2, 2 * w)
     assert f32_hex(v2) == f32_hex(v_dev)
     assert np.array_equal(inter[:, 0::2].view(np.uint32), m_dev.view(np.uint32)) and np.all(inter[:, 1::2] == -7.0)
+    # a bottom-up map (negative ssimStride): rows land in reverse order
+    flip = np.full((h, w), -7.0, np.float32)
+    v3 = host_call(a, b, 1, w, a.ctypes.data, 1, w, b.ctypes.data, w, h, flip.ctypes.data + 4 * (h - 1) * w, 1, -w)
+    assert f32_hex(v3) == f32_hex(v_dev)
+    assert np.array_equal(flip[::-1].view(np.uint32), m_dev.view(np.uint32))
     # every band count the pipeline can be asked for gives the same bits (own processes: the default context reads the env once)
     if (w, h) == (3000, 1237):
         code = ("import sys, numpy as np; sys.path.insert(0, %r); import oracle, ssim_amd; a,b=oracle.synth_pair(%d,%d,0x5EED); "
