@@ -23,7 +23,7 @@ Timing: barrier + synchronize on both sides of exactly K steps, max over ranks; 
 all ranks / that time.  Before any timing the results are gated on the reference's known answers
 (FMA path float bits) -- on every rank's first pairs.
 
-After the headline the same run times the other BASELINE.json configs on rank 0 (8192^2 + map exact
+After the headline a single-GPU run times the other BASELINE.json configs (8192^2 + map exact
 and separable, 128 x 1080p, fp64 internals 4096^2 + map), each KAT-gated, into `configs`.
 
 Only the cpu_baseline leg touches oracle/: it times the real reference kernels (oracle/_ref,
@@ -526,7 +526,7 @@ def main():
 
     # --- the other BASELINE configs, rank 0 only, after the timed region (kernel time from HIP events) ---
     configs = {}
-    if rank == 0 and not args.no_configs and args.mode == 0 and args.variant == 0 and args.strip_rows == 0:
+    if rank == 0 and world == 1 and not args.no_configs and args.mode == 0 and args.variant == 0 and args.strip_rows == 0:
         del batch                                  # free the headline batch first
         torch.cuda.empty_cache()
         ksteps = max(args.steps // 2, 5)
