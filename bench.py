@@ -14,8 +14,7 @@ else (RANK / LOCAL_RANK / WORLD_SIZE set) it is simply one of the ranks.
 A "step" is one pass of the hot path over one batch: distinct synthetic pairs (seeds 0x5EED+i,
 SURVEY.md 8(d)) resident in HBM, one batched launch per rank through the C ABI
 (rmgr_ssim_hip_enqueue_batch), and -- for N > 1 -- one RCCL all-reduce of the per-image fp64 sums so
-that every rank holds every result (issued asynchronously: it overlaps the next step's kernels, every
-one of the K collectives is complete before the closing fence).  Images are sharded by rank:
+that every rank holds every result.  Images are sharded by rank:
     --scaling weak   (default) every rank owns PAIRS pairs: per-GPU work is fixed;
     --scaling strong the workload's total batch (e.g. BASELINE.json configs[3]: 1024 x 1080p) is split
                      over the ranks with sharding.split_batch: total work is fixed.
@@ -382,16 +381,7 @@ def main():
         # all-reduce of the per-image partial sums; other ranks contribute exact zeros
         return sharding.exchange_sums(sums_all, work, dist)
 
-    pipe = sharding.PipelinedExchange(sums_all, dist)
-
-    def timed_step():
-        if mine:
-            ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
-        # the all-reduce of this step overlaps the next step's kernels (two alternating result vectors)
-        return pipe.step()
-
     def fence():
-        pipe.drain()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -422,7 +412,7 @@ def main():
         step()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        timed_step()
+        step()
     fence()
     # HIP events bracket the main kernel of every timed step, on the stream it is launched on
     # (rmgr_ssim_hip_set_profiling): two event records per ~3 ms step, read back after the fence.
@@ -430,15 +420,14 @@ def main():
     ctx.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        timed_step()
+        step()
     fence()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
-    # what the pipelined exchange delivered last must be the vector the gate checked, bit for bit
-    last = pipe.drain()
-    torch.cuda.synchronize()
+    # the last step must have delivered the vector the gate checked, bit for bit
+    last = work if dist is not None else sums_all
     if not np.array_equal(last.cpu().numpy().view(np.uint64), full.cpu().numpy().view(np.uint64)):
-        raise SystemExit("rank %d: the pipelined exchange returned different sums than the gated step" % rank)
+        raise SystemExit("rank %d: the timed steps returned different sums than the gated step" % rank)
     launches, kernel_ms = ctx.get_profile()
     kernel_avg_ms = kernel_ms / max(launches, 1)
     if dist is not None:

@@ -36,40 +36,3 @@ def exchange_sums(sums_all, work, dist):
     dist.all_reduce(work)
     return work
 
-
-class PipelinedExchange(object):
-    """The same exchange for a loop of steps, overlapped with the next step's kernels: two result vectors alternate,
-    the all-reduce of step k is issued asynchronously (on the collective's own stream, ordered after the copy of
-    step k's sums) and only awaited when its vector is needed again, two steps later -- or by drain().  On xGMI the
-    8 B-per-pair all-reduce is latency-bound (tens of microseconds); this keeps it off the compute stream's critical path."""
-
-    def __init__(self, sums_all, dist):
-        self.sums_all, self.dist = sums_all, dist
-        self.active = dist is not None and dist.is_initialized()
-        self.bufs = [sums_all.clone(), sums_all.clone()] if self.active else []
-        self.handles = [None, None]
-        self.k = 0
-
-    def step(self):
-        """Call after this step's kernels were enqueued on the current stream.  Returns the tensor that will hold every
-        rank's sums once the collective has completed (valid after drain(), or after a later wait on its handle)."""
-        if not self.active:
-            return self.sums_all
-        i = self.k & 1
-        self.k += 1
-        if self.handles[i] is not None:
-            self.handles[i].wait()            # the current stream waits for the collective of two steps ago
-        self.bufs[i].copy_(self.sums_all)
-        self.handles[i] = self.dist.all_reduce(self.bufs[i], async_op=True)
-        return self.bufs[i]
-
-    def drain(self):
-        """Make the current stream wait for every outstanding collective; returns the most recent result vector."""
-        last = self.sums_all
-        for i in (self.k & 1, (self.k + 1) & 1):      # older first
-            if self.handles[i] is not None:
-                self.handles[i].wait()
-                self.handles[i] = None
-        if self.active and self.k:
-            last = self.bufs[(self.k - 1) & 1]
-        return last
