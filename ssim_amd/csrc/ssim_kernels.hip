@@ -1154,6 +1154,15 @@ hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b
     return hipGetLastError();
 }
 
+// Waves per SIMD each kernel runs at (its VGPR count): what plan() packs strips with.
+static int waves_per_simd(int mode, int variant)
+{
+    if (mode == MODE_DOUBLE) return 3;                       // 160 VGPRs
+    if (mode == MODE_FAST) return 3;                         // two columns: 164-166 VGPRs; one column: 105 (4 waves, planned as 3)
+    return 2;                                                // bit-exact modes: 233 VGPRs (one column without map: 146, planned as 2)
+    (void)variant;
+}
+
 static int columns_per_lane(int mode, int variant)
 {
     if (mode == MODE_DOUBLE) return 1;
@@ -1177,30 +1186,36 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.y_end = (y_rows >= height - g.y_begin) ? height : g.y_begin + y_rows;
     const uint32_t rows_total = g.y_end - g.y_begin;
     auto round8 = [cr](uint32_t v) { return (v + cr - 1) & ~(cr - 1); };      // up to whole cells
-    if (strip_rows <= 0) {
-        // Default: tall strips amortise the 10 halo rows, but the launch still needs a few waves per SIMD on
-        // every CU.  512-row strips when that leaves >= 32 strips per CU (measured +1.5 % on 32 x 4096^2 over 256,
-        // a loss with fewer); otherwise the candidate with the lowest cost under a small model fitted to
-        // measurements (u = rows + 10 halo rows is a strip's length, S = the number of SIMDs):
-        //   up to one strip per SIMD     1.37 u     (a wave that has its SIMD to itself runs ~1.46x faster than a sharing one)
-        //   up to two strips per SIMD    2 u        (the SIMDs holding two waves finish last)
-        //   more                         n u / S + 0.3 u   (throughput-bound, plus a tail)
-        // taller winning ties.  A launch that cannot fill the GPU is thereby cut into short strips: 256^2 runs as
-        // 64 strips of 8 rows in half the time of 16 strips of 32.  Strips are then evened out (1080 rows ->
-        // 5 x 216 rather than 4 x 256 + 56) so that no wave gets a short one, in whole reduction cells.
+    if (strip_rows <= 0 && rows_total > 0) {
+        // Default: the strip height with the lowest cost under a DISCRETE model of how the launch's n strips (of u =
+        // rows + 10 halo rows + ~2 rows of setup each) pack onto the chip's wave slots -- fitted to strip-height sweeps
+        // (profiles/r02_rows_sweep_*.txt; the continuous model of round 1 was off by up to 36 % for mid-size launches:
+        // 16 x 1080p ran 9 strips per column = 2160 waves, 112 more than the 2048 slots, i.e. two rounds):
+        //   a SIMD holds `waves` strips at a time (2 for the bit-exact two-column kernel, 3 for MODE_FAST / MODE_DOUBLE);
+        //   full rounds of waves x SIMDs strips cost u each; the last, partial round costs u x f(k) where k = how many
+        //   waves the fullest SIMD still holds: a wave alone on its SIMD runs 1.46x (2-wave kernels) / 2.05x (3-wave
+        //   kernels) faster than in a full house, two of three 1.4x faster.
+        // Candidates: every even split of the rows into 1 .. rows/cell strips of whole reduction cells, at most 512
+        // rows tall (taller measured no better, and less friendly to the L2 on 64 x 4096^2); taller wins ties.
         const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
-        auto strips = [&](uint32_t rows) { return (uint64_t)g.strips_x * ((rows_total + rows - 1) / rows) * count; };
-        auto evened = [&](uint32_t rows) { const uint32_t ny = rows_total ? (rows_total + rows - 1) / rows : 1; return rows_total ? round8((rows_total + ny - 1) / ny) : rows; };
-        uint32_t rows = 512;
-        if (strips(rows) < cus * 32) {
-            uint64_t best = ~(uint64_t)0;
-            for (uint32_t cand = 256; cand >= cr; cand >>= 1) {
-                const uint64_t n = strips(cand), u = evened(cand) + 10;
-                const uint64_t cost = n <= simds ? 137 * u : n <= 2 * simds ? 200 * u : 100 * n * u / simds + 30 * u;
-                if (cost < best) { best = cost; rows = cand; }
-            }
+        const int waves = waves_per_simd(mode, variant);
+        static const uint32_t tail2[2] = {685, 1000}, tail3[3] = {490, 715, 1000};      // x 1/1000
+        const uint32_t* tail = waves >= 3 ? tail3 : tail2;
+        const uint64_t slots = simds * (uint64_t)(waves >= 3 ? 3 : 2);
+        uint64_t best = ~(uint64_t)0;
+        uint32_t best_rows = round8(rows_total < 512 ? rows_total : 512);
+        const uint32_t ny_min = (rows_total + 511) / 512, ny_max = (rows_total + cr - 1) / cr;
+        for (uint32_t ny = ny_min; ny <= ny_max; ++ny) {
+            const uint32_t rows = round8((rows_total + ny - 1) / ny);
+            const uint32_t ny_eff = (rows_total + rows - 1) / rows;
+            if (ny_eff != ny) continue;                                   // the same split as a smaller ny
+            const uint64_t n = (uint64_t)g.strips_x * ny * count, u = rows + 12;
+            const uint64_t full = n / slots, rem = n % slots;
+            const uint64_t last = rem == 0 ? 0 : tail[(rem - 1) / simds];
+            const uint64_t cost = u * (full * 1000 + last);
+            if (cost < best) { best = cost; best_rows = rows; }
         }
-        strip_rows = (int)evened(rows);
+        strip_rows = (int)best_rows;
     }
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = round8((uint32_t)strip_rows);      // strips start on cell boundaries

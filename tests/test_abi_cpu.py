@@ -238,9 +238,13 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
         assert (p.stripsX - 1) * p.stripWidth < w <= p.stripsX * p.stripWidth
         assert (p.stripsY - 1) * p.stripRows < h <= p.stripsY * p.stripRows
         assert p.wavefronts == p.stripsX * p.stripsY * n
-    assert ssim_amd.get_plan(1920, 1080, 128).stripRows == 216          # 5 even strips, not 4 x 256 + 56
-    assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 512           # >= 32 strips per CU left
-    assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # a single image still gets 8 waves per CU
+    # the discrete wave-slot model (ssim_kernels.hip plan()): 2 x 1024 SIMDs = 2048 slots for the bit-exact kernel
+    assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 512           # 8192 strips = four full rounds
+    assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # 2048 strips: exactly one round
+    p = ssim_amd.get_plan(1920, 1080, 16)
+    assert (p.stripRows, p.stripsY, p.wavefronts) == (136, 8, 1920)     # one round; 9 strips per column would be 2160 = two rounds
+    p = ssim_amd.get_plan(1920, 1080, 128)
+    assert p.stripRows % 8 == 0 and p.stripsY * p.stripRows >= 1080 > (p.stripsY - 1) * p.stripRows and p.stripRows <= 512
     assert ssim_amd.get_plan(256, 256, 1).stripWidth == 64              # tiny launches: twice as many, half as wide strips
     assert ssim_amd.get_plan(1024, 1024, 1).stripWidth == 128 and ssim_amd.get_plan(256, 256, 64).stripWidth == 128
     # strips start on the boundaries of the fp64 reduction cells: 32 rows for images of >= 2048 rows, else 8
