@@ -8,6 +8,9 @@
  */
 #ifndef RMGR_SSIM_OPENMP_H
 #define RMGR_SSIM_OPENMP_H
+#ifndef RMGR_SSIM_OMP_H
+    #define RMGR_SSIM_OMP_H      /* the reference's guard name (ssim-openmp.h:21), for code that tests it */
+#endif
 
 #include <rmgr/ssim.h>
 

@@ -64,3 +64,35 @@ def gpu_ctx():
     ctx = ssim_amd.Context(0)
     yield ctx
     ctx.close()
+
+
+# ---- the reference's full-size test sets (tests/golden/images + refsets.json; tests/tools/make_refset_fixtures.py) --
+IMAGES = os.path.join(GOLDEN, "images")
+_decoded = {}
+
+
+@pytest.fixture(scope="session")
+def refsets():
+    with open(os.path.join(GOLDEN, "refsets.json")) as f:
+        return json.load(f)["sets"]
+
+
+def _decode_rgb(name):
+    if name not in _decoded:
+        from PIL import Image
+        _decoded[name] = np.array(Image.open(os.path.join(IMAGES, name)).convert("RGB"))
+        if len(_decoded) > 4:                      # a 1080p RGB frame is 6 MB: keep the cache small
+            _decoded.pop(next(k for k in _decoded if k != name and not k.endswith(".png")))
+    return _decoded[name]
+
+
+def refset_pair(entry):
+    """Decoded planes of one (pair, channel) of refsets.json.  The pixels must be the ones the expected outputs were
+    generated from: a decoder that produces anything else fails the test loudly (nothing is compared on other pixels)."""
+    import hashlib
+    a = _decode_rgb(entry["a_file"])[:entry["height"], :entry["width"], entry["channel"]]
+    b = _decode_rgb(entry["b_file"])[:entry["height"], :entry["width"], entry["channel"]]
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    assert hashlib.sha256(a.tobytes()).hexdigest() == entry["a_sha256"], "PNG decode differs from the fixture generator's: " + entry["a_file"]
+    assert hashlib.sha256(b.tobytes()).hexdigest() == entry["b_sha256"], "JPEG decode differs from the fixture generator's (PIL/libjpeg version?): " + entry["b_file"]
+    return a, b

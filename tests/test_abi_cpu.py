@@ -286,3 +286,101 @@ def test_kernels_keep_two_waves_per_simd_and_never_spill():
         if "strip2_kernelILi1E" in k or "strip1_kernelILi2E" in k:      # MODE_FAST (two columns) and MODE_DOUBLE: three waves per SIMD
             assert v["VGPRs"] <= 168 and v["Occupancy"] >= 3, (k, v)
         assert v["LDS"] <= 8192, (k, v)                 # 8 resident waves per CU must fit their slots in 64 KiB at most
+
+
+# ---- the header's public macro surface (reference include/rmgr/ssim.h:28-376) --------------------------------------
+MACRO_TU = os.path.join(ROOT, "tests", "src", "macro_surface.c")
+CLANG = "/opt/rocm/lib/llvm/bin/clang"
+# every macro name the reference header defines for its includers (collected from the reference header; the names are API)
+REFERENCE_MACROS = """RMGR_COMPILER_IS_NOT_DOXYGEN RMGR_COMPILER_IS_DOXYGEN RMGR_COMPILER_IS_CLANG RMGR_COMPILER_IS_MSVC RMGR_COMPILER_IS_GCC
+RMGR_COMPILER_IS_GCC_OR_CLANG RMGR_COMPILER_VERSION_MAJOR RMGR_COMPILER_VERSION_MINOR RMGR_COMPILER_VERSION_PATCH
+RMGR_COMPILER_VERSION_IS_AT_LEAST RMGR_COMPILER_IS_CLANG_AT_LEAST RMGR_COMPILER_IS_MSVC_AT_LEAST RMGR_COMPILER_IS_GCC_AT_LEAST
+RMGR_COMPILER_IS_CLANG_LESS_THAN RMGR_COMPILER_IS_MSVC_LESS_THAN RMGR_COMPILER_IS_GCC_LESS_THAN RMGR_WARNING_PUSH RMGR_WARNING_POP
+RMGR_WARNING_MSVC_DISABLE RMGR_WARNING_GCC_DISABLE RMGR_WARNING_CLANG_DISABLE RMGR_DEPRECATED RMGR_DEPRECATED_MSG RMGR_ALIGNED_VAR
+RMGR_ARCH_IS_X86_32 RMGR_ARCH_IS_X86_64 RMGR_ARCH_IS_X86_ANY RMGR_ARCH_IS_ARM_32 RMGR_ARCH_IS_ARM_64 RMGR_ARCH_IS_ARM_ANY
+RMGR_ARCH_IS_LITTLE_ENDIAN RMGR_ARCH_IS_BIG_ENDIAN RMGR_CPP_VERSION RMGR_NOEXCEPT RMGR_NOEXCEPT_TYPEDEF RMGR_FORCEINLINE RMGR_NOINLINE
+RMGR_COMPILER_SUPPORTS_ARM_NEON RMGR_UINT8_MAX RMGR_SSIM_H""".split()
+
+
+@pytest.mark.parametrize("cc", ["gcc -std=c89 -x c", "g++ -std=c++98 -x c++", "g++ -std=c++17 -x c++",
+                                CLANG + " -std=c89 -x c", CLANG + "++ -std=c++98 -x c++", CLANG + "++ -std=c++17 -x c++"])
+def test_macro_surface_compiles_pedantic_and_runs(tmp_path, cc):
+    """every macro the reference header exports, used the way its callers use them
+    (src/ssim-cli.cpp:46-59,:357; sample/rmgr-ssim-sample.cpp:33-38; tests/rmgr-ssim-tests.cpp:35-52,:67,:486,:497;
+    tests/ssim_naive.h:28,:60), as C89, C++98 and C++17 under -pedantic -Werror, with gcc and clang."""
+    if not os.path.exists(cc.split()[0]) and "/" in cc.split()[0]:
+        pytest.skip("no " + cc.split()[0])
+    obj = str(tmp_path / "ms.o")
+    r = subprocess.run(cc.split() + ["-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + INCLUDE, "-c", MACRO_TU, "-o", obj], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    main = tmp_path / "main.c"
+    main.write_text("#ifdef __cplusplus\nextern \"C\"\n#endif\nint macro_surface_selftest(void);\nint main(void) { return macro_surface_selftest(); }\n")
+    exe = str(tmp_path / "ms")
+    r = subprocess.run(cc.split() + [str(main), "-x", "none", obj, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert subprocess.run([exe]).returncode == 0
+
+
+def _macro_dump(header_dir, cc, tmp_path, tag):
+    """the value each macro of REFERENCE_MACROS expands to with the header under header_dir (object-like ones evaluated
+    by the preprocessor where they are integer expressions, everything else as expansion text)"""
+    src = tmp_path / ("dump_%s.c" % tag)
+    lines = ["#include <rmgr/ssim.h>"]
+    for m in REFERENCE_MACROS:
+        lines.append("#ifdef %s\nDEFINED \"%s\"\n#else\nUNDEFINED \"%s\"\n#endif" % (m, m, m))
+    for m in ("RMGR_COMPILER_IS_DOXYGEN", "RMGR_COMPILER_IS_CLANG", "RMGR_COMPILER_IS_MSVC", "RMGR_COMPILER_IS_GCC", "RMGR_COMPILER_IS_GCC_OR_CLANG",
+              "RMGR_ARCH_IS_X86_32", "RMGR_ARCH_IS_X86_64", "RMGR_ARCH_IS_X86_ANY", "RMGR_ARCH_IS_ARM_32", "RMGR_ARCH_IS_ARM_64", "RMGR_ARCH_IS_ARM_ANY",
+              "RMGR_ARCH_IS_LITTLE_ENDIAN", "RMGR_ARCH_IS_BIG_ENDIAN", "RMGR_COMPILER_SUPPORTS_ARM_NEON", "RMGR_COMPILER_VERSION_IS_AT_LEAST(1,2,3)",
+              "RMGR_COMPILER_VERSION_IS_AT_LEAST(99,0,0)", "RMGR_COMPILER_IS_GCC_AT_LEAST(5,1,0)", "RMGR_COMPILER_IS_GCC_LESS_THAN(5,1,0)",
+              "RMGR_COMPILER_IS_CLANG_AT_LEAST(5,1,0)", "RMGR_COMPILER_IS_CLANG_LESS_THAN(5,1,0)", "RMGR_COMPILER_IS_MSVC_AT_LEAST(5,1,0)",
+              "RMGR_COMPILER_IS_MSVC_LESS_THAN(5,1,0)"):
+        lines.append("#if %s\nTRUE \"%s\"\n#else\nFALSE \"%s\"\n#endif" % (m, m, m))
+    for m in ("RMGR_COMPILER_VERSION_MAJOR", "RMGR_COMPILER_VERSION_MINOR", "RMGR_COMPILER_VERSION_PATCH", "RMGR_CPP_VERSION", "RMGR_NOEXCEPT",
+              "RMGR_NOEXCEPT_TYPEDEF", "RMGR_WARNING_GCC_DISABLE(\"-Wx\")", "RMGR_WARNING_CLANG_DISABLE(\"-Wx\")", "RMGR_WARNING_MSVC_DISABLE(1)",
+              "RMGR_DEPRECATED", "RMGR_DEPRECATED_MSG(\"m\")", "RMGR_ALIGNED_VAR(16, int, v)", "RMGR_NOINLINE"):
+        lines.append("EXPANDS \"%s\" = %s" % (m.replace("\"", "'"), m))
+    src.write_text("\n".join(lines) + "\n")
+    r = subprocess.run(cc.split() + ["-E", "-P", "-I" + header_dir, str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    keep = [l.strip() for l in r.stdout.splitlines() if l.strip().split(" ")[0] in ("DEFINED", "UNDEFINED", "TRUE", "FALSE", "EXPANDS")]
+    return keep
+
+
+@pytest.mark.parametrize("cc", ["gcc -std=c99 -x c", "g++ -std=c++98 -x c++", "g++ -std=c++17 -x c++", CLANG + "++ -std=c++17 -x c++",
+                                # other targets, preprocessor only (freestanding: the compiler's own stddef.h / stdint.h)
+                                CLANG + " -std=c99 -x c -ffreestanding --target=aarch64-none-elf",
+                                CLANG + " -std=c99 -x c -ffreestanding --target=armv7-none-eabi -mfpu=neon",
+                                CLANG + " -std=c99 -x c -ffreestanding --target=i686-none-elf",
+                                CLANG + " -std=c99 -x c -ffreestanding --target=powerpc64-none-elf",
+                                "g++ -std=c++17 -x c++ -DRMGR_ARCH_IS_BIG_ENDIAN=1 -DRMGR_COMPILER_IS_GCC=0"])
+def test_macro_surface_has_the_reference_values(tmp_path, cc):
+    """Where the reference tree is present (build container): every macro is defined by both headers or by neither, the
+    integer-valued ones evaluate alike and the attribute / pragma ones expand to the same tokens."""
+    ref = "/root/reference/include"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    if not os.path.exists(cc.split()[0]) and "/" in cc.split()[0]:
+        pytest.skip("no " + cc.split()[0])
+    # the reference header needs the cmake-generated <rmgr/ssim-version.h>?  no: only src/ssim.cpp includes it
+    ours = _macro_dump(INCLUDE, cc, tmp_path, "ours")
+    theirs = _macro_dump(ref, cc, tmp_path, "ref")
+    assert len(ours) > 60
+    squeeze = lambda l: re.sub(r"\s+", "", l).replace("__inline__", "inline")   # RMGR_FORCEINLINE here is also valid in C89
+    diff = [(a, b) for a, b in zip(ours, theirs) if squeeze(a) != squeeze(b)]
+    assert not diff and len(ours) == len(theirs), diff[:10]
+
+
+def test_reference_naive_header_compiles_against_this_header(tmp_path):
+    """The reference's header-only test oracle (tests/ssim_naive.h) includes <rmgr/ssim.h> and uses RMGR_COMPILER_IS_GCC /
+    RMGR_NOEXCEPT: it must compile, and instantiate, against THIS repository's header (build container only)."""
+    if not os.path.exists("/root/reference/tests/ssim_naive.h"):
+        pytest.skip("reference tree not present (GPU box)")
+    tu = tmp_path / "naive_tu.cpp"
+    tu.write_text("#include <ssim_naive.h>\n"
+                  "double probe(const rmgr::ssim::GeneralParams& p, double* map)\n"
+                  "{ return rmgr::ssim::naive::compute_ssim<double, rmgr::ssim::uint8_t>(p.width, p.height, p.imgA.topLeft, p.imgA.step, p.imgA.stride,\n"
+                  "      p.imgB.topLeft, p.imgB.step, p.imgB.stride, map, 1, p.width); }\n")
+    for std in ("gnu++98", "gnu++17"):      # the __float128 literals of ssim_naive.h:72 need the GNU dialect, with the reference header too
+        r = subprocess.run(["g++", "-std=" + std, "-D_USE_MATH_DEFINES", "-fsyntax-only", "-Wall", "-I" + INCLUDE, "-I/root/reference/tests", str(tu)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
