@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RMGR_SSIM_LIB") or os.path.join(_HERE, "lib", "librmgr-ssim-hip.so")   # env override: A/B builds in tools/
 
-MODE_EXACT, MODE_FAST, MODE_DOUBLE, MODE_UNFUSED = 0, 1, 2, 3
+MODE_EXACT, MODE_FAST, MODE_DOUBLE, MODE_UNFUSED, MODE_SEPARABLE = 0, 1, 2, 3, 4
 
 c_pd = ctypes.c_ssize_t  # ptrdiff_t
 

@@ -103,16 +103,22 @@ int map_hip_error(hipError_t e)
 struct DeviceGuard {
     int prev, rc;
     bool restore;
-    explicit DeviceGuard(int dev) : prev(-1), rc(0), restore(false)
+    DeviceGuard() : prev(-1), rc(0), restore(false) {}          // inactive until enter()
+    explicit DeviceGuard(int dev) : prev(-1), rc(0), restore(false) { enter(dev); }
+    int enter(int dev)
     {
         if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
         if (prev != dev) {
             const hipError_t e = hipSetDevice(dev);
-            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); return; }
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); return rc; }
             restore = prev >= 0;
         }
+        return 0;
     }
     ~DeviceGuard() { if (restore) (void)hipSetDevice(prev); }
+private:
+    DeviceGuard(const DeviceGuard&);
+    DeviceGuard& operator=(const DeviceGuard&);
 };
 #define USE_DEVICE(c) DeviceGuard device_guard_((c)->device); if (device_guard_.rc) return device_guard_.rc
 
@@ -268,11 +274,18 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
         if (slot >= 0) { (void)hipStreamSynchronize(c->stream); c->desc_slots[slot].live = 0; }   // the table upload may still be queued
         return map_hip_error(err);
     }
-    if ((rc = commit_events(c, eb, ee))) return rc;
+    // the launch is queued and reads the slot's device table: mark the slot busy BEFORE anything else can fail
     if (slot >= 0) {
-        HIP_TRY(hipEventRecord(c->desc_slots[slot].used, c->stream));
+        const hipError_t e = hipEventRecord(c->desc_slots[slot].used, c->stream);
+        if (e != hipSuccess) {              // cannot track the reader: wait for it instead of leaving the table unprotected
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->stream);
+            release_events(c, eb, ee);
+            return map_hip_error(e);
+        }
         c->desc_slots[slot].in_flight = true;
     }
+    if ((rc = commit_events(c, eb, ee))) return rc;
     return 0;
 }
 
@@ -472,7 +485,7 @@ rmgr_ssim_hip_Context* default_context(int* err)
         g_default_err = rmgr_ssim_hip_create(&g_default, dev, NULL);
         if (g_default && g_default_err == 0) {
             const char* m = getenv("RMGR_SSIM_HIP_MODE");
-            if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_UNFUSED) g_default->mode = atoi(m);
+            if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_SEPARABLE) g_default->mode = atoi(m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
             else g_default->mode = RMGR_SSIM_HIP_MODE_DOUBLE;
 #endif
@@ -585,7 +598,7 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode) RMGR_NOEXCEPT
 {
-    if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_UNFUSED) return EINVAL;
+    if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_SEPARABLE) return EINVAL;
     if (!c) {
         // the process-wide default context of the drop-in entry points (what rmgr::ssim::select_impl switches)
         int rc = 0;
@@ -881,6 +894,8 @@ namespace {
 struct StagedPair {
     rmgr_ssim_hip_Context* c;
     std::unique_lock<std::mutex> guard;
+    DeviceGuard device;           // the context's device stays current for as long as the staged pair lives, i.e. for the WHOLE
+                                  // entry point: its later allocations, events and launches must not land on the caller's device
     uint8_t* a; uint8_t* b;       // device copies of the two interleaved images, rows `pitch` bytes apart
     size_t pitch;
 };
@@ -899,7 +914,7 @@ int stage_interleaved(rmgr_ssim_hip_Context* c, StagedPair& sp, const void* out1
         sp.guard = std::unique_lock<std::mutex>(c->lock);
     }
     sp.c = c;
-    USE_DEVICE(c);
+    if ((rc = sp.device.enter(c->device))) return rc;
     sp.pitch = ((size_t)width * channels + 3) & ~(size_t)3;      // dword-aligned rows for the packed luminance path
     const size_t bytes = sp.pitch * height + 4;
     if ((rc = grow_device(c->stage_a, c->stage_a_cap, bytes))) return rc;

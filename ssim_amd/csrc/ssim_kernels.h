@@ -17,7 +17,10 @@ struct PairDesc {
     float*         map; int64_t map_step, map_stride;
 };
 
-enum Mode { MODE_EXACT = 0, MODE_FAST = 1, MODE_DOUBLE = 2, MODE_UNFUSED = 3 };
+// MODE_FAST: the three E[.] planes in the reference's exact order, the two mu planes separable (inside north_star's
+// FMA-relative tolerance on all of the reference's test sets); MODE_SEPARABLE: everything separable, four planes, centred
+// pixels (closer to the exact value than the reference itself, but not correlated with the reference's rounding).
+enum Mode { MODE_EXACT = 0, MODE_FAST = 1, MODE_DOUBLE = 2, MODE_UNFUSED = 3, MODE_SEPARABLE = 4 };
 
 struct Geometry {
     uint32_t width, height, count;
@@ -70,7 +73,7 @@ inline int default_variant(uint32_t width, uint32_t height, uint32_t count, int 
 {
     if (mode != MODE_EXACT && mode != MODE_UNFUSED) return 0;
     const uint64_t strips = (uint64_t)((width + 127) / 128) * ((height + 7) / 8) * count;
-    return strips * 4 <= (uint64_t)(cu_count > 0 ? cu_count : 256) * 4 ? 1 : 0;
+    return strips <= (uint64_t)(cu_count > 0 ? cu_count : 256) ? 1 : 0;      // fewer strips than CUs (a quarter of the SIMDs)
 }
 
 // Rows per cell of the fp64 reduction: a function of the image height ONLY, so that every launch that touches an

@@ -32,7 +32,7 @@
 #include <type_traits>
 
 // Cache policy of the map stores: nt (non-temporal).  The map is written once and never read by the kernel; as ordinary
-// write-back lines it competes with the input rows for L2 and costs MODE_FAST 18 % with a map (8192^2: 333 -> 391 Gpix/s
+// write-back lines it competes with the input rows for L2 and costs the separable mode 18 % with a map (8192^2: 333 -> 391 Gpix/s
 // with nt; MODE_EXACT +2.7 %; profiles/r02_map_store_ab.txt).
 #define SSIM_MAP_STORE_AUX 2
 
@@ -165,20 +165,15 @@ __device__ __forceinline__ d2 ring_fma(d2 h, double g, d2 c)
     return d;
 }
 
-// Separable blur (MODE_FAST fp32 / MODE_DOUBLE fp64): 1-D pass along the row on the folded
+// Separable blur (MODE_SEPARABLE and the mu streams of MODE_FAST in fp32 / MODE_DOUBLE fp64): 1-D pass along the row on the folded
 // sums, then the vertical pass as the same ring scatter.  g[] = centre..edge taps of the true
 // 1-D Gaussian (g(x)g(y) equals the 2-D kernel of tests/ssim_naive.h to 7e-18).
 //
-// ORDER: the order in which the row pass adds its six terms (tap index 0 = centre .. 5 = edge).  In fp32 the order
-// matters for the GLOBAL value: centre first -- the reference's own order -- rounds with a systematic drift, and
-// through sigma^2 = E[x^2] - mu^2 the mu planes carry almost all of it into the mean (einstein/jpg: -1.7e-6 against
-// the double oracle; the reference FMA path itself is -1.55e-6).  MODE_FAST answers to two tolerances that pull
-// apart on that image -- the reference's test tolerance against the exact value (2e-6) and north_star's against the
-// FMA path (1.5e-6) -- and uses the orders that sit between the two with the widest margins on the 18 fixtures
-// (tests/tools/fast_mode_model.py reproduces the kernel's arithmetic on the CPU and tabulates the candidates):
-//   mu streams     ORDER_INNER_FIRST   2,1,0,3,4,5
-//   E[.] streams   ORDER_SMALL_FIRST   5,4,3,2,1,0
-// -> worst global error 9.5e-7 vs the oracle, 6.0e-7 vs the FMA path.  Same instruction count for every order.
+// ORDER: the order in which the row pass adds its six terms (tap index 0 = centre .. 5 = edge).  Every fp32 user now
+// adds them centre first -- the reference's own order (src/ssim_fma.cpp:203-243), chosen without looking at any image.
+// (Round 2 picked other orders per stream on the 18 small fixtures to steer the global value between two tolerances;
+// on the reference's full-size sets that tuning did not hold -- DESIGN.md section 2 -- and it is gone.  The other two
+// orders stay available to tests/tools/fast_mode_model.py's study of them.)
 enum { ORDER_CENTRE_FIRST = 0, ORDER_SMALL_FIRST = 1, ORDER_INNER_FIRST = 2 };
 template <int ORDER> __device__ constexpr int tap_at(int k)
 {
@@ -300,33 +295,68 @@ __device__ __forceinline__ f2 ssim_px2_tail(const Px2& h, f2 eAB, float c1, floa
     return div_inrange_finish(n, h.den, h.rcp);
 }
 
-// MODE_FAST works on FOUR blurred planes, not five: the SSIM formula needs the two variances only as their sum,
-// sigma_a^2 + sigma_b^2 = E[a^2 + b^2] - (mu_a^2 + mu_b^2), so a^2 + b^2 (an exact integer <= 130050 in fp32) is
-// blurred as one plane.  A fifth of the blur work, of the accumulator registers and of the staged LDS bytes goes away,
-// and the ab plane can share a float2 with it -- (a^2 + b^2, ab) per pixel -- which packs like the (a, b) plane does.
-// One pixel, scalar form (the one-column kernel); the packed form below performs the same operations on both columns
-// of a lane, so the two kernels agree bit for bit.
-template <typename T>
-__device__ __forceinline__ T ssim_px_fast(T muA, T muB, T eS, T eX, T c1, T c2)
+// MODE_SEPARABLE and MODE_DOUBLE work on FOUR blurred planes, not five: the SSIM formula needs the two variances only as
+// their sum, sigma_a^2 + sigma_b^2 = E[a^2 + b^2] - (mu_a^2 + mu_b^2), so a^2 + b^2 is blurred as one plane.  A fifth of
+// the blur work, of the accumulator registers and of the staged LDS bytes goes away, and the ab plane can share a float2
+// with it -- (a^2 + b^2, ab) per pixel -- which packs like the (a, b) plane does.
+//
+// Correctly rounded n/d in fp64 for the same operand ranges as div_inrange_* above (d in [2^8, 2^35], n = 0 or
+// 2^-16 <= |n| <= 2^35: no scaling, no fix-up needed): an fp32 reciprocal seed (v_rcp_f32: 1 ulp of 2^-23), two Newton
+// steps in fp64 (2^-46, then below 2^-53), the quotient and one residual correction.  The compiler's generic sequence
+// for a double division is v_div_scale_f64 x2, the quarter-rate v_rcp_f64, eight v_fma_f64, v_div_fmas, v_div_fixup.
+__device__ __forceinline__ double div_inrange(double n, double d)
 {
-    const T muAB = muA * muB;
-    const T tm = muA * muA + muB * muB;            // mul, mul, add: three roundings (-ffp-contract=off)
-    const T ts = eS - tm, sAB = eX - muAB;
-    const T num = fma_(T(2), muAB, c1) * fma_(T(2), sAB, c2);     // 2x is exact: the one rounding of 2x + c
-    const T den = (tm + c1) * (ts + c2);
-    return num / den;
+    double r = (double)__builtin_amdgcn_rcpf((float)d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
 }
-// mu0, mu1 = (mu_a, mu_b) of the lane's two columns; e0, e1 = (E[a^2+b^2], E[ab]) of the two columns
-__device__ __forceinline__ f2 ssim_px2_fast(f2 mu0, f2 mu1, f2 e0, f2 e1, float c1, float c2)
+// One pixel of MODE_DOUBLE (uncentred moments: fp64 has the headroom).
+__device__ __forceinline__ double ssim_px_four(double muA, double muB, double eS, double eX, double c1, double c2)
 {
-    const f2 m0 = mu0 * mu0, m1 = mu1 * mu1;
-    const f2 muAB = {opaque(mu0.x * mu0.y), opaque(mu1.x * mu1.y)};
-    const f2 tm = {opaque(m0.x + m0.y), opaque(m1.x + m1.y)};
-    const f2 ts = {opaque(e0.x - tm.x), opaque(e1.x - tm.y)};
-    const f2 sAB = {opaque(e0.y - muAB.x), opaque(e1.y - muAB.y)};
+    const double muAB = muA * muB;
+    const double tm = muA * muA + muB * muB;       // mul, mul, add: three roundings (-ffp-contract=off)
+    const double ts = eS - tm, sAB = eX - muAB;
+    const double num = __builtin_fma(2.0, muAB, c1) * __builtin_fma(2.0, sAB, c2);     // 2x is exact: the one rounding of 2x + c
+    const double den = (tm + c1) * (ts + c2);
+    return div_inrange(num, den);
+}
+
+// MODE_SEPARABLE blurs CENTRED pixels a' = a - 128, b' = b - 128 (exact in fp32): variance and covariance do not move
+// with the origin, sigma_a^2 + sigma_b^2 = E[a'^2 + b'^2] - (mu_a'^2 + mu_b'^2), sigma_ab = E[a'b'] - mu_a' mu_b', but the
+// cancellation that dominates fp32 SSIM error -- E[x^2] - mu^2 with both near 65025 in bright flat areas, against
+// c2 = 58.5 -- now happens between numbers of at most 16384 (32768 for the sum plane): the worst per-pixel error
+// against the exact value drops from 6.9e-4 to 1.9e-4 on the reference's test sets (tests/tools/fast_mode_model.py) for
+// two subtractions per staged pixel and a handful of operations per output pixel.  The luminance term uses mu = mu' + 128.
+// Scalar form (the one-column kernel); the packed form below performs the same operations on both columns of a lane, so
+// the two kernels agree bit for bit.
+constexpr float kCentre = 128.0f;
+__device__ __forceinline__ float ssim_px_sep(float mA, float mB, float eS, float eX, float c1, float c2)
+{
+    const float sS = eS - (mA * mA + mB * mB), sAB = eX - mA * mB;       // from the centred moments
+    const float muA = mA + kCentre, muB = mB + kCentre;
+    const float muAB = muA * muB, tm = muA * muA + muB * muB;
+    const f2 n = {__builtin_fmaf(2.0f, muAB, c1) * __builtin_fmaf(2.0f, sAB, c2), 0.0f};
+    const f2 d = {(tm + c1) * (sS + c2), 1.0f};
+    return div_inrange_finish(n, d, div_inrange_rcp(d)).x;
+}
+// m0, m1 = centred (mu_a', mu_b') of the lane's two columns; e0, e1 = (E[a'^2 + b'^2], E[a'b']) of the two columns
+__device__ __forceinline__ f2 ssim_px2_sep(f2 m0, f2 m1, f2 e0, f2 e1, float c1, float c2)
+{
+    const f2 q0 = m0 * m0, q1 = m1 * m1;
+    const f2 pc = {opaque(m0.x * m0.y), opaque(m1.x * m1.y)};            // mu_a' mu_b'
+    const f2 tc = {opaque(q0.x + q0.y), opaque(q1.x + q1.y)};            // mu_a'^2 + mu_b'^2
+    const f2 sS = {opaque(e0.x - tc.x), opaque(e1.x - tc.y)};
+    const f2 sAB = {opaque(e0.y - pc.x), opaque(e1.y - pc.y)};
+    const f2 off = {kCentre, kCentre};
+    const f2 u0 = m0 + off, u1 = m1 + off;                               // (mu_a, mu_b)
+    const f2 v0 = u0 * u0, v1 = u1 * u1;
+    const f2 muAB = {opaque(u0.x * u0.y), opaque(u1.x * u1.y)};
+    const f2 tm = {opaque(v0.x + v0.y), opaque(v1.x + v1.y)};
     const f2 two = {2.0f, 2.0f}, C1 = {c1, c1}, C2 = {c2, c2};
     const f2 n = fma_(two, muAB, C1) * fma_(two, sAB, C2);
-    const f2 den = (tm + C1) * (ts + C2);
+    const f2 den = (tm + C1) * (sS + C2);
     return div_inrange_finish(n, den, div_inrange_rcp(den));      // operand ranges as for ssim_px2_head/tail
 }
 
@@ -492,19 +522,29 @@ struct Slot2 {
 
 enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 
-// MODE_FAST (round 2): four planes -- the (a,b) pair plane and the (a^2 + b^2, ab) pair plane (ssim_px_fast above),
-// both float2 per pixel, so the lane's four packed streams are (a,b) and (a^2+b^2, ab) of each of its two columns;
-// the `q` member of the slot holds the second plane, `xx` is not used.  14 window reads per lane-row (round 1: 20).
+// MODE_FAST (round 3): the HYBRID.  The three E[.] streams -- (a^2,b^2) of each column and ab -- run the reference's
+// exact operation order (blur_exact) and are bit-identical to the reference's planes; only the two (a,b) streams, i.e.
+// mu_a and mu_b, use the separable blur (centre-first row pass, fused column pass).  Why this split: on the reference's
+// own test sets the FMA path's per-pixel error against the exact value is almost entirely the rounding of the E[.]
+// planes (reference mu + exact E: 6.5e-4 from the reference; exact mu + reference E: 2.2e-4), and on bbb1080 that error
+// (6.46e-4) is larger than north_star's FMA-relative tolerance (6.3e-4) -- so an implementation can only be inside
+// the tolerance by REPRODUCING those roundings, and the mu planes are where it can afford not to.  51 -> 22 lane-ops
+// per pixel on two of the five planes: 278 -> 220 per pixel.  Epilogue, LDS layout, rings: MODE_EXACT's.
+// MODE_SEPARABLE (round 2's MODE_FAST, now on centred pixels): four planes -- the (a',b') pair plane and the
+// (a'^2 + b'^2, a'b') pair plane (ssim_px2_sep above), both float2 per pixel, so the lane's four packed streams are
+// (a',b') and (a'^2+b'^2, a'b') of each of its two columns; the `q` member of the slot holds the second plane, `xx`
+// is not used.  14 window reads per lane-row (round 1: 20).
 // Measured before that, on the five-plane form (profiles/r02_fast_lds_attack.md, r02_fast_interleave_ab.txt):
 // products formed in registers instead of staged +3.3...4.4 %, interleaved row passes +1.4 %.
 // MAP: 0 no map; 1 map with any ssimStep (one 4-byte store per column); 2 every pair of the launch has ssimStep == 1
 // and the width is even (no lane owns a lone last column): the lane's two adjacent values go out as one 8-byte store
-// (a wave writes 512 contiguous bytes per row; +2...3 % for MODE_FAST with a map, neutral for MODE_EXACT).
+// (a wave writes 512 contiguous bytes per row; +2...3 % for MODE_SEPARABLE with a map, neutral for MODE_EXACT).
 template <int MODE, int MAP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_FAST ? 3 : 2, MODE == MODE_FAST ? 3 : 2)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_SEPARABLE ? 3 : 2, MODE == MODE_SEPARABLE ? 3 : 2)))
 void ssim_strip2_kernel(const KArgs args)
 {
-    constexpr bool FAST = (MODE == MODE_FAST);
+    constexpr bool FAST = (MODE == MODE_SEPARABLE);  // the four-plane, three-waves-per-SIMD flow of the row loop
+    constexpr bool HYB = (MODE == MODE_FAST);        // MODE_EXACT's flow with separable (a,b) streams
     constexpr int PAD = Slot2::PAD, ROW_PX = Slot2::ROW_PX;
     constexpr int NLOAD = 3;                         // pixels each lane stages per row
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
@@ -544,7 +584,7 @@ void ssim_strip2_kernel(const KArgs args)
     }
 
     // One row of pixels is in flight in registers (requested an iteration, ~1 us, before it is staged).
-    // A second row in flight was measured: no gain in MODE_EXACT, -3 % in MODE_FAST (registers).
+    // A second row in flight was measured: no gain in MODE_EXACT, -3 % in the separable mode (registers).
     uint8_t va[NLOAD], vb[NLOAD];
     auto fetch_to = [&](int r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
         const int ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
@@ -564,13 +604,14 @@ void ssim_strip2_kernel(const KArgs args)
         float* xf = reinterpret_cast<float*>(s.xx);
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            const float a = (float)ia[t], b = (float)ib[t];   // retrieve_tile: uint8 -> Float
+            float a = (float)ia[t], b = (float)ib[t];         // retrieve_tile: uint8 -> Float
+            if constexpr (FAST) { a -= kCentre; b -= kCentre; }   // centred pixels (ssim_px_sep); exact
             const f2 ab = {a, b};
             const float x = a * b;                            // multiply (exact for 8-bit inputs)
             const int p = sp[t];
             s.ab[p] = ab;
             if constexpr (FAST) {
-                s.q[p] = f2{__builtin_fmaf(b, b, a * a), x};      // (a^2 + b^2, ab): exact integers
+                s.q[p] = f2{__builtin_fmaf(b, b, a * a), x};      // (a'^2 + b'^2, a'b'): exact integers
             } else {
                 s.q[p] = ab * ab;
                 xf[2 * p] = x;                          // xx[p].lo
@@ -683,15 +724,15 @@ void ssim_strip2_kernel(const KArgs args)
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!FAST) {
+        if constexpr (!FAST && !HYB) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
         } else {
             const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
             const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
-            blur_separable_pair<ORDER_INNER_FIRST>(accAB[0], accAB[1], s0, s1, gf);
+            blur_separable_pair<ORDER_CENTRE_FIRST>(accAB[0], accAB[1], s0, s1, gf);
         }
-        // (4) the (a*a,b*b) streams / MODE_FAST: the (a*a + b*b, ab) streams
+        // (4) the (a*a,b*b) streams / MODE_SEPARABLE: the (a'*a' + b'*b', a'b') streams
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FAST) {
 #pragma unroll
@@ -705,7 +746,7 @@ void ssim_strip2_kernel(const KArgs args)
         } else {
             const f2 s0[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
             const f2 s1[6] = {wq[7], wq[8] + wq[6], wq[9] + wq[5], wq[10] + wq[4], wq[11] + wq[3], wq[12] + wq[2]};
-            blur_separable_pair<ORDER_SMALL_FIRST>(accQ[0], accQ[1], s0, s1, gf);
+            blur_separable_pair<ORDER_CENTRE_FIRST>(accQ[0], accQ[1], s0, s1, gf);
             asm volatile("" :: "v"(wq[0]), "v"(wq[13]));
         }
         Px2 head;
@@ -732,7 +773,7 @@ void ssim_strip2_kernel(const KArgs args)
         // map offset up front.
         if constexpr (phase != ROW_WARMUP) {
             f2 v;
-            if constexpr (FAST) v = ssim_px2_fast(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
+            if constexpr (FAST) v = ssim_px2_sep(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
             else                v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
             colsum[0] += (double)v.x;               // fp64 accumulation, src/ssim_avx.cpp:357-358
             colsum[1] += (double)v.y;
@@ -764,7 +805,7 @@ void ssim_strip2_kernel(const KArgs args)
             wave_sync();
         }
         if constexpr (phase != ROW_LAST && FAST) {
-            // MODE_FAST runs three waves per SIMD (168 VGPRs): the next row's (a,b) window is requested only now, so
+            // MODE_SEPARABLE runs three waves per SIMD (168 VGPRs): the next row's (a,b) window is requested only now, so
             // that its 28 registers are not live during the streams above, and folded behind the staging of row r+2
             // (the other two waves cover the latency).
             __builtin_amdgcn_sched_barrier(0);
@@ -812,9 +853,10 @@ void ssim_strip2_kernel(const KArgs args)
 //  * the fully general fallback of the fp32 modes: 64-bit coordinates and per-lane 64-bit offsets
 //    (image pairs fits_strip2() rejects) and tuning variant 1.  In fp32 it has half the accumulator
 //    registers of the two-column kernel but twice the loader/LDS work per pixel: 10-14 % slower
-//    (MODE_FAST: 25 % slower, although it runs four waves per SIMD there).
-// MODE_EXACT / MODE_UNFUSED: five planes, the ab plane a scalar stream.  MODE_FAST / MODE_DOUBLE: the four planes
-// of ssim_px_fast -- (a,b) and (a*a + b*b, ab) -- as two packed streams; MODE_DOUBLE then needs 160 VGPRs and runs
+//    (MODE_SEPARABLE: 25 % slower, although it runs four waves per SIMD there).
+// MODE_EXACT / MODE_UNFUSED / MODE_FAST: five planes, the ab plane a scalar stream (MODE_FAST: separable (a,b) stream).
+// MODE_SEPARABLE / MODE_DOUBLE: the four planes of ssim_px_sep / ssim_px_four -- (a,b) and (a*a + b*b, ab), centred in
+// MODE_SEPARABLE -- as two packed streams; MODE_DOUBLE then needs 160 VGPRs and runs
 // three waves per SIMD (five planes: 193 VGPRs, two waves; 8 x 4096^2 163 -> 214 Gpix/s).
 // ---------------------------------------------------------------------------------------------
 struct Slot1 {
@@ -830,8 +872,9 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     constexpr int PAD = Slot1::PAD, ROW_PX = Slot1::ROW_PX;
     constexpr int NLOAD = 2;
     constexpr bool DBL = (MODE == MODE_DOUBLE);
-    constexpr bool FAST = (MODE == MODE_FAST);
-    constexpr bool FOUR = FAST || DBL;               // four planes: (a,b) and (a*a + b*b, ab), see ssim_px_fast
+    constexpr bool FAST = (MODE == MODE_SEPARABLE);
+    constexpr bool HYB = (MODE == MODE_FAST);        // exact E[.] streams, separable (a,b) stream
+    constexpr bool FOUR = FAST || DBL;               // four planes: (a,b) and (a*a + b*b, ab), see ssim_px_sep / ssim_px_four
     constexpr bool FUSED = (MODE != MODE_UNFUSED);
     typedef typename std::conditional<DBL, d2, f2>::type PV;         // plane-pair streams
     typedef typename std::conditional<DBL, double, float>::type XV;  // ab stream
@@ -871,7 +914,8 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     auto stage_from = [&](Slot1& s, const uint8_t (&ia)[NLOAD], const uint8_t (&ib)[NLOAD]) {
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            const float a = (float)ia[t], b = (float)ib[t];
+            float a = (float)ia[t], b = (float)ib[t];
+            if constexpr (FAST) { a -= kCentre; b -= kCentre; }   // centred pixels (ssim_px_sep); exact
             const f2 ab = {a, b};
             s.ab[sp[t]] = ab;
             if constexpr (FOUR) {
@@ -927,9 +971,9 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     fold_ab();
 
     auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream) {
-        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
-        else if constexpr (FAST)   // the same tap orders as the two-column kernel: the two agree bit for bit
-            blur_separable<decltype(mu_stream)::value ? ORDER_INNER_FIRST : ORDER_SMALL_FIRST>(acc, s0, s1, s2, s3, s4, s5, args.gf);
+        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED || (HYB && !decltype(mu_stream)::value)) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
+        else if constexpr (FAST || HYB)   // the same tap order as the two-column kernel: the two agree bit for bit
+            blur_separable<ORDER_CENTRE_FIRST>(acc, s0, s1, s2, s3, s4, s5, args.gf);
         else  // fp64 internals: the folded sums are exact integers in fp32; everything after is double
             blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
     };
@@ -959,11 +1003,11 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         if constexpr (phase != ROW_WARMUP) {         // ring entry 0 is the finished output row y = r - 5
             float vmap;
             if constexpr (DBL) {
-                const double v = ssim_px_fast(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1d, args.c2d);
+                const double v = ssim_px_four(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1d, args.c2d);
                 colsum += v;
                 vmap = (float)v;                    // the reference's map is float in the double build too
             } else if constexpr (FAST) {
-                const float v = ssim_px_fast(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1, args.c2);
+                const float v = ssim_px_sep(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, args.c1, args.c2);
                 colsum += (double)v;
                 vmap = v;
             } else {
@@ -1157,10 +1201,10 @@ hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b
 // Waves per SIMD each kernel runs at (its VGPR count): what plan() packs strips with.
 static int waves_per_simd(int mode, int variant)
 {
-    if (mode == MODE_DOUBLE) return 3;                       // 160 VGPRs
-    if (mode == MODE_FAST) return 3;                         // two columns: 164-166 VGPRs; one column: 105 (4 waves, planned as 3)
-    return 2;                                                // bit-exact modes: 233 VGPRs (one column without map: 146, planned as 2)
     (void)variant;
+    if (mode == MODE_DOUBLE) return 3;                       // 160 VGPRs
+    if (mode == MODE_SEPARABLE) return 3;                    // two columns: 164-166 VGPRs; one column: 105 (4 waves, planned as 3)
+    return 2;                                                // bit-exact modes and MODE_FAST: 233 VGPRs (one column without map: 146, planned as 2)
 }
 
 static int columns_per_lane(int mode, int variant)
@@ -1185,13 +1229,13 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.y_begin = (y_begin < height ? y_begin : height) & ~(cr - 1);
     g.y_end = (y_rows >= height - g.y_begin) ? height : g.y_begin + y_rows;
     const uint32_t rows_total = g.y_end - g.y_begin;
-    auto round8 = [cr](uint32_t v) { return (v + cr - 1) & ~(cr - 1); };      // up to whole cells
+    auto round_cell = [cr](uint32_t v) { return (v + cr - 1) & ~(cr - 1); };      // up to whole cells
     if (strip_rows <= 0 && rows_total > 0) {
         // Default: the strip height with the lowest cost under a DISCRETE model of how the launch's n strips (of u =
         // rows + 10 halo rows + ~2 rows of setup each) pack onto the chip's wave slots -- fitted to strip-height sweeps
         // (profiles/r02_rows_sweep_*.txt; the continuous model of round 1 was off by up to 36 % for mid-size launches:
         // 16 x 1080p ran 9 strips per column = 2160 waves, 112 more than the 2048 slots, i.e. two rounds):
-        //   a SIMD holds `waves` strips at a time (2 for the bit-exact two-column kernel, 3 for MODE_FAST / MODE_DOUBLE);
+        //   a SIMD holds `waves` strips at a time (2 for the bit-exact two-column kernel and MODE_FAST, 3 for MODE_SEPARABLE / MODE_DOUBLE);
         //   full rounds of waves x SIMDs strips cost u each; the last, partial round costs u x f(k) where k = how many
         //   waves the fullest SIMD still holds: a wave alone on its SIMD runs 1.46x (2-wave kernels) / 2.05x (3-wave
         //   kernels) faster than in a full house, two of three 1.4x faster.
@@ -1203,10 +1247,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         const uint32_t* tail = waves >= 3 ? tail3 : tail2;
         const uint64_t slots = simds * (uint64_t)(waves >= 3 ? 3 : 2);
         uint64_t best = ~(uint64_t)0;
-        uint32_t best_rows = round8(rows_total < 512 ? rows_total : 512);
+        uint32_t best_rows = round_cell(rows_total < 512 ? rows_total : 512);
         const uint32_t ny_min = (rows_total + 511) / 512, ny_max = (rows_total + cr - 1) / cr;
         for (uint32_t ny = ny_min; ny <= ny_max; ++ny) {
-            const uint32_t rows = round8((rows_total + ny - 1) / ny);
+            const uint32_t rows = round_cell((rows_total + ny - 1) / ny);
             const uint32_t ny_eff = (rows_total + rows - 1) / rows;
             if (ny_eff != ny) continue;                                   // the same split as a smaller ny
             const uint64_t n = (uint64_t)g.strips_x * ny * count, u = rows + 12;
@@ -1218,7 +1262,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         strip_rows = (int)best_rows;
     }
     if (strip_rows < 1) strip_rows = 1;
-    g.strip_rows = round8((uint32_t)strip_rows);      // strips start on cell boundaries
+    g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries
     g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
     return g;
 }
@@ -1290,6 +1334,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
     case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
     case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
+    case MODE_SEPARABLE: err = one ? launch_strip1<MODE_SEPARABLE>(geo, ka, map, stream) : launch_strip2<MODE_SEPARABLE>(geo, ka, map, stream); break;
     case MODE_DOUBLE:  err = launch_strip1<MODE_DOUBLE>(geo, ka, map, stream); break;
     default:           return hipErrorInvalidValue;
     }

@@ -1,10 +1,11 @@
-"""GPU: the two non-default arithmetic modes.
+"""GPU: the non-default arithmetic modes on the small fixtures and at BASELINE's full sizes (the reference's full-size
+image sets are in tests/test_gpu_refsets.py).
 
-MODE_FAST   separable fp32 blur; north_star tolerance versus the FMA reference:
-            global |d| <= 1.5e-6, per-pixel |d| <= 6.3e-4 (README.md:89-92 of the reference).
-MODE_DOUBLE RMGR_SSIM_USE_DOUBLE semantics (BASELINE.json config 5): per-pixel error versus
-            tests/ssim_naive.h <= 1e-7, here against the committed naive maps and the oracle's
-            restatement of it.
+MODE_FAST       reference-order E[.] planes + separable mu planes; north_star's tolerance versus the FMA reference:
+                global |d| <= 1.5e-6, per-pixel |d| <= 6.3e-4 (README.md:89-92 of the reference).
+MODE_SEPARABLE  everything separable; the reference's test tolerances versus its double oracle (2e-6 / 1e-3).
+MODE_DOUBLE     RMGR_SSIM_USE_DOUBLE semantics (BASELINE.json config 5): per-pixel error versus tests/ssim_naive.h <= 1e-7,
+                here against the committed naive maps and the oracle's restatement of it.
 """
 import os
 
@@ -46,17 +47,26 @@ def test_fast_mode_within_documented_tolerance(gpu_ctx, manifest, oracle, varian
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
         gpu_ctx.set_tuning(0, 0)
     print("fast mode worst global %.3g, worst per-pixel %.3g" % (worst_g, worst_p))
+    assert worst_g <= 8.5e-7 and worst_p <= 1.6e-4          # the CPU model's numbers on these 18 pairs: 7.7e-7 / 1.4e-4
 
 
-def test_fast_mode_full_size_4k(gpu_ctx, oracle):
-    """MODE_FAST at BASELINE's 4096^2 size: every pixel and the global value inside the tolerance."""
-    gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+@pytest.mark.parametrize("mode", [ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE])
+def test_fast_modes_full_size_4k(gpu_ctx, oracle, mode):
+    """BASELINE's 4096^2 size, every pixel: MODE_FAST inside north_star's tolerance versus the FMA path; MODE_SEPARABLE inside
+    the reference's test tolerance versus the double oracle (whose full 4096^2 map the 64-thread oracle computes in seconds)."""
+    threads = oracle.oracle_lib().oracle_max_threads()
+    gpu_ctx.set_mode(mode)
     try:
         a, b = oracle.synth_pair(4096, 4096, 0x5EED)
-        ov, _, om = oracle.ssim_f32(a, b, want_map=True, threads=oracle.oracle_lib().oracle_max_threads())
         v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
-        assert abs(float(v) - float(ov)) <= GLOBAL_TOL
-        assert float(np.abs(m.astype(np.float64) - om.astype(np.float64)).max()) <= PIXEL_TOL
+        if mode == ssim_amd.MODE_FAST:
+            ov, _, om = oracle.ssim_f32(a, b, want_map=True, threads=threads)
+            assert abs(float(v) - float(ov)) <= GLOBAL_TOL
+            assert float(np.abs(m.astype(np.float64) - om.astype(np.float64)).max()) <= PIXEL_TOL
+        else:
+            nv, _, nm = oracle.ssim_naive_f64(a, b, want_map=True, threads=threads)
+            assert abs(float(v) - nv) < 2e-6
+            assert float(np.abs(m.astype(np.float64) - nm).max()) < 1e-3
     finally:
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
 
@@ -79,9 +89,9 @@ def test_double_mode_vs_naive_oracle(gpu_ctx, manifest, oracle):
 
 
 def test_double_mode_4k_config5(gpu_ctx, oracle, manifest):
-    """BASELINE.json config 5 at full size: 4096^2, fp64 internals, map on; per-pixel vs the naive
-    oracle on sampled windows (the naive 121-tap gather is too slow for 16.7 Mpx on the CPU) and
-    the global value vs the reference's naive<double> known answer."""
+    """BASELINE.json config 5 at full size: 4096^2, fp64 internals, map on: EVERY pixel of the 16.7 Mpixel map within 1e-7
+    of the naive double oracle (all host threads: a few seconds), as the reference's tests assert every pixel
+    (tests/rmgr-ssim-tests.cpp:315-326), and the global value vs the reference's naive<double> known answer."""
     gpu_ctx.set_mode(ssim_amd.MODE_DOUBLE)
     keep = []
     try:
@@ -92,12 +102,13 @@ def test_double_mode_4k_config5(gpu_ctx, oracle, manifest):
         v = gpu_ctx.compute_device(p)
         assert abs(float(v) - 0.893428737869049) <= 6e-8 + 1e-9     # SURVEY.md 8(d) KAT, naive<double>
         m = dm.download(np.float32, (4096, 4096))
-        for (y0, x0) in ((0, 0), (0, 4096 - 256), (4096 - 256, 0), (1900, 2000), (4096 - 256, 4096 - 256)):
-            ys, xs = slice(y0, y0 + 256), slice(x0, x0 + 256)
-            _, _, nm = oracle.ssim_naive_f64(np.ascontiguousarray(a[ys, xs]), np.ascontiguousarray(b[ys, xs]), want_map=True, threads=8)
-            iy = slice(0 if y0 == 0 else 5, 256 if y0 + 256 == 4096 else 251)
-            ix = slice(0 if x0 == 0 else 5, 256 if x0 + 256 == 4096 else 251)
-            assert float(np.abs(m[ys, xs][iy, ix].astype(np.float64) - nm[iy, ix]).max()) <= 1e-7
+        nv, _, nm = oracle.ssim_naive_f64(a, b, want_map=True, threads=oracle.oracle_lib().oracle_max_threads())
+        assert abs(nv - 0.893428737869049) < 1e-14
+        worst = 0.0
+        for y in range(0, 4096, 512):                              # in slabs: no second 128 MB temporary
+            worst = max(worst, float(np.abs(m[y:y + 512].astype(np.float64) - nm[y:y + 512]).max()))
+        print("double mode 4096^2: worst pixel vs naive %.3e" % worst)
+        assert worst <= 1e-7
     finally:
         for d in keep:
             d.free()
