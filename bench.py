@@ -55,10 +55,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH
 # VALU work per output pixel, lane-ops: exact = 5 planes x (5 fold adds + 6 mul + 30 fma + 10 ring adds) = 255
 # + 23 for the SSIM formula / divide / fp64 accumulate; fast (hybrid) = 3 reference-order planes x 51 + 2 separable planes
 # x 22 + 23; separable = 4 planes x 22 + 23 + 8 (a^2 + b^2 is blurred as one plane; centring and the restored mu);
-# fp64 mode, counted in fp64-rate issue slots: 4 planes x (6 row + 11 column) fp64 ops + 24 fp32->fp64 conversions of the
-# folded sums + 12 (formula) + 10 (in-range division incl. the fp32 seed and its conversions) + 2 (map value, column sum);
-# the 20 fold adds are packed fp32 (10 slots)
-VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 126, 3: 278, 4: 119}
+# fp64 mode: VALU ISSUE SLOTS per pixel counted in the compiled hot loop (tools/isa_mix.py: 294 VALU instructions per two
+# rows of one pixel per lane) -- 88 fp64 multiply-adds of the blur and the formula, 25 fp32->fp64 conversions of the folded
+# sums, 10 packed fold adds, 24 of staging / addressing / in-range division / map value; every non-packed instruction
+# occupies one fp64-rate slot, which is what the 39.3 T/s peak counts (round 2 counted the 88 blur operations only)
+VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 147, 3: 278, 4: 119}
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
@@ -228,7 +229,7 @@ def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
     t = ops * px / sec / 1e12
     return ({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
              "algorithmic_bytes_per_launch": px * bpp},
-            {"achieved": round(t, 2), "peak": peak, "unit": "T fp64 lane-ops/s" if mode == 2 else "T lane-ops/s",
+            {"achieved": round(t, 2), "peak": peak, "unit": "T fp64-rate issue slots/s" if mode == 2 else "T lane-ops/s",
              "frac": round(t / peak, 4), "ops_per_pixel": ops})
 
 
@@ -310,6 +311,18 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
             "roofline": roof, "valu": valu}
 
 
+def shard_table(args, world):
+    """Which global pairs [first, last) each of `world` ranks owns, and the batch size: the one place the timed run takes
+    its sharding from."""
+    from ssim_amd import sharding
+    _, _, weak_pairs, strong_total, _, _, _ = WORKLOADS[args.workload]
+    if args.scaling == "weak":
+        per = args.pairs or weak_pairs
+        return {"scaling": "weak", "total": world * per, "shards": [list(sharding.shard_range(r, world, per)) for r in range(world)]}
+    total = args.pairs or strong_total
+    return {"scaling": "strong", "total": total, "shards": [list(x) for x in sharding.split_batch(total, world)]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,11 +337,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
     ap.add_argument("--print-launch", action="store_true", help="print the rank launcher command for --gpus N and exit (no GPU needed)")
+    ap.add_argument("--print-shards", action="store_true", help="print the shard table (JSON: which global pairs each rank owns) for --gpus N and exit (no GPU needed)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.print_launch:
         print(" ".join(launcher_command(args.gpus, [a for a in sys.argv[1:] if a != "--print-launch"])))
+        return 0
+    if args.print_shards:
+        print(json.dumps(shard_table(args, args.gpus)))
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])
@@ -374,13 +391,9 @@ def main():
 
     W, H, weak_pairs, strong_total, want_map, kats, workload_desc = WORKLOADS[args.workload]
     # --- shard the batch by image: rank r owns global pairs [first, last) ---
-    if args.scaling == "weak":
-        P = args.pairs or weak_pairs
-        first, last = sharding.shard_range(rank, world, P)
-        total = world * P
-    else:
-        total = args.pairs or strong_total
-        first, last = sharding.split_batch(total, world)[rank]
+    table = shard_table(args, world)
+    total = table["total"]
+    first, last = table["shards"][rank]
     mine = last - first
     batch = Batch(torch, ssim_amd, synth, ctx, dev, W, H, first, mine, want_map)
     sums_all = torch.zeros(total, dtype=torch.float64, device=dev)       # zero except this rank's slice

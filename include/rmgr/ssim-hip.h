@@ -10,6 +10,7 @@
  *   rmgr_ssim_hip_compute_ssim_host    rmgr::ssim::compute_ssim           src/ssim.cpp:933-1106
  *   rmgr_ssim_hip_compute_ssim_device  same, images/map already in HBM    src/ssim.cpp:933-1106
  *   rmgr_ssim_hip_compute_ssim_batch_host  a caller's loop over host pairs  sample/rmgr-ssim-sample.cpp:84-95
+ *   rmgr_ssim_hip_compute_ssim_batch_host_devices  the same over several GPUs   src/ssim.cpp:1048-1088 (thread-pool dispatch)
  *   rmgr_ssim_hip_enqueue_batch        the caller-side loop over pairs    src/ssim-cli.cpp:197-210
  *                                      + per-thread fp64 partials         src/ssim.cpp:902-926
  *   rmgr_ssim_hip_finalize             the final mean                     src/ssim.cpp:1090-1103
@@ -118,6 +119,20 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32
  */
 rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
                                                    float* ssim) RMGR_NOEXCEPT;
+
+/*
+ * The same batch of HOST pairs sharded BY IMAGE over several devices from ONE process ("one process
+ * x 8 devices"): contiguous blocks of the batch -- the first count % n one pair longer -- one per entry of `devices`
+ * (NULL: every visible device, deviceCount ignored), each on its own worker thread and engine context (created on first
+ * use, cached), each through the pipelined staging of rmgr_ssim_hip_compute_ssim_batch_host.  No image data crosses
+ * devices and, in one address space, there is no exchange step either: every ssim[i] is written by the worker that owns
+ * pair i and is bit-identical to the single-device result, whatever the device list.  A device may be listed more than
+ * once (several contexts on one GPU).  `mode` is the arithmetic of every worker.  Stands in for the reference's
+ * thread-pool dispatch (src/ssim.cpp:1048-1088, src/ssim-openmp.c:26-47) at batch granularity.  Blocking; one call at a
+ * time per process.  EINVAL for a device index that is not visible, ENODEV without devices.
+ */
+rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host_devices(const rmgr_int32_t* devices, rmgr_uint32_t deviceCount, rmgr_int32_t mode,
+                                                           rmgr_uint32_t count, const rmgr_ssim_Params* params, float* ssim) RMGR_NOEXCEPT;
 
 /* ssim[i] = float(sums[i] / double(width*height)) with the reference's 32-bit product (src/ssim.cpp:1102).  Host arrays. */
 rmgr_int32_t rmgr_ssim_hip_finalize(rmgr_uint32_t count, const double* sums, rmgr_uint32_t width, rmgr_uint32_t height, float* ssim) RMGR_NOEXCEPT;

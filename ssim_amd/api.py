@@ -64,7 +64,8 @@ C_SYMBOLS = [
     "rmgr_ssim_compute_ssim", "rmgr_ssim_compute_ssim_openmp",
     "rmgr_ssim_hip_get_device_count", "rmgr_ssim_hip_create", "rmgr_ssim_hip_destroy", "rmgr_ssim_hip_set_mode",
     "rmgr_ssim_hip_get_mode", "rmgr_ssim_hip_set_tuning", "rmgr_ssim_hip_get_plan", "rmgr_ssim_hip_compute_ssim_host",
-    "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_compute_ssim_batch_host", "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
+    "rmgr_ssim_hip_compute_ssim_device", "rmgr_ssim_hip_compute_ssim_batch_host", "rmgr_ssim_hip_compute_ssim_batch_host_devices",
+    "rmgr_ssim_hip_enqueue_batch", "rmgr_ssim_hip_finalize",
     "rmgr_ssim_hip_synchronize", "rmgr_ssim_hip_malloc", "rmgr_ssim_hip_free", "rmgr_ssim_hip_memcpy_h2d",
     "rmgr_ssim_hip_memcpy_d2h", "rmgr_ssim_hip_set_profiling", "rmgr_ssim_hip_get_profile", "rmgr_ssim_hip_describe",
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
@@ -111,6 +112,7 @@ def load_library(path=None):
         "rmgr_ssim_hip_compute_ssim_device": [vp, ctypes.POINTER(ctypes.c_float), PP],
         "rmgr_ssim_hip_enqueue_batch": [vp, u32, PP, vp],
         "rmgr_ssim_hip_compute_ssim_batch_host": [vp, u32, PP, ctypes.POINTER(ctypes.c_float)],
+        "rmgr_ssim_hip_compute_ssim_batch_host_devices": [ctypes.POINTER(i32), u32, i32, u32, PP, ctypes.POINTER(ctypes.c_float)],
         "rmgr_ssim_hip_finalize": [u32, ctypes.POINTER(ctypes.c_double), u32, u32, ctypes.POINTER(ctypes.c_float)],
         "rmgr_ssim_hip_synchronize": [vp],
         "rmgr_ssim_hip_malloc": [vp, ctypes.POINTER(vp), ctypes.c_size_t],
@@ -222,6 +224,22 @@ def compute_ssim_batch(pairs, ctx=None):
     out = (ctypes.c_float * n)()
     _check("rmgr_ssim_hip_compute_ssim_batch_host", lib.rmgr_ssim_hip_compute_ssim_batch_host(ctx.handle if ctx is not None else None, n, params, out))
     return np.array(out[:], np.float32)
+
+
+def compute_ssim_batch_devices(pairs, devices=None, mode=MODE_EXACT):
+    """compute_ssim_batch() sharded by image over `devices` (a list of device indices; None: all visible) from this one
+    process (rmgr_ssim_hip_compute_ssim_batch_host_devices)."""
+    lib = load_library()
+    n = len(pairs)
+    params = (Params * max(n, 1))()
+    for i, (a, b) in enumerate(pairs):
+        h, w = a.shape
+        params[i] = make_params(w, h, a.ctypes.data, a.strides[1], a.strides[0], b.ctypes.data, b.strides[1], b.strides[0])
+    out = (ctypes.c_float * max(n, 1))()
+    devs = (ctypes.c_int32 * len(devices))(*devices) if devices is not None else None
+    _check("rmgr_ssim_hip_compute_ssim_batch_host_devices",
+           lib.rmgr_ssim_hip_compute_ssim_batch_host_devices(devs, len(devices) if devices is not None else 0, mode, n, params, out))
+    return np.array(out[:n], np.float32)
 
 
 def compute_ssim_channels(a, b, want_map=False):

@@ -887,6 +887,89 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     return 0;
 }
 
+// ---- one process, several devices ------------------------------------------------------------------------------------
+// The reference parallelises one call over a caller-supplied thread pool (tile jobs, src/ssim.cpp:1048-1088; the OpenMP
+// adapter src/ssim-openmp.c:26-47).  The batch-level counterpart here: a contiguous block of the pairs per device, one
+// worker thread and one cached engine context per device slot, every block through the pipelined host-batch path above.
+// Pairs are independent and every ssim[i] is written by exactly one worker, so there is no exchange step at all in one
+// address space (the RCCL all-reduce exists for the one-process-per-GPU form, rmgr_ssim_hip_comm_*), and ssim[i] is
+// bit-identical to the single-device call for any device list.
+namespace {
+std::mutex g_slots_lock;
+std::vector<std::pair<int, rmgr_ssim_hip_Context*> > g_slots;     // (device, context) per slot of the last device lists; never freed
+std::mutex g_multi_lock;                                          // one multi-device call at a time (the slots are shared)
+
+rmgr_ssim_hip_Context* slot_context(size_t slot, int device, int* err)
+{
+    std::lock_guard<std::mutex> guard(g_slots_lock);
+    try {
+        if (g_slots.size() <= slot) g_slots.resize(slot + 1, std::make_pair(-1, (rmgr_ssim_hip_Context*)NULL));
+    } catch (...) { *err = ENOMEM; return NULL; }
+    if (g_slots[slot].second && g_slots[slot].first != device) {     // the slot served another device last time
+        rmgr_ssim_hip_destroy(g_slots[slot].second);
+        g_slots[slot].second = NULL;
+    }
+    if (!g_slots[slot].second) {
+        *err = rmgr_ssim_hip_create(&g_slots[slot].second, device, NULL);
+        if (*err) { g_slots[slot].second = NULL; return NULL; }
+        g_slots[slot].first = device;
+    }
+    return g_slots[slot].second;
+}
+} // namespace
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host_devices(const rmgr_int32_t* devices, rmgr_uint32_t deviceCount, rmgr_int32_t mode,
+                                                                      rmgr_uint32_t count, const rmgr_ssim_Params* params, float* ssim) RMGR_NOEXCEPT
+{
+    if (count && (!params || !ssim)) return EINVAL;
+    if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_SEPARABLE) return EINVAL;
+    if (devices && deviceCount == 0) return EINVAL;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess) { (void)hipGetLastError(); visible = 0; }
+    if (visible <= 0) return ENODEV;
+    std::vector<int> devs;
+    try {
+        if (devices) devs.assign(devices, devices + deviceCount);
+        else for (int d = 0; d < visible; ++d) devs.push_back(d);
+    } catch (...) { return ENOMEM; }
+    for (size_t k = 0; k < devs.size(); ++k)
+        if (devs[k] < 0 || devs[k] >= visible) return EINVAL;
+    if (count == 0) return 0;
+    std::lock_guard<std::mutex> one_call(g_multi_lock);
+    const size_t n = std::min<size_t>(devs.size(), count);          // no more workers than pairs
+    // contiguous blocks, the first count % n slots one pair longer (ssim_amd/sharding.py split_batch)
+    std::vector<int> rcs;
+    std::vector<std::thread> workers;
+    try { rcs.assign(n, 0); workers.reserve(n); } catch (...) { return ENOMEM; }
+    struct Job {
+        static void run(size_t slot, int device, int mode, uint32_t first, uint32_t cnt, const rmgr_ssim_Params* params, float* ssim, int* rc)
+        {
+            rmgr_ssim_hip_Context* c = slot_context(slot, device, rc);
+            if (!c) return;
+            if ((*rc = rmgr_ssim_hip_set_mode(c, mode))) return;
+            *rc = rmgr_ssim_hip_compute_ssim_batch_host(c, cnt, params + first, ssim + first);
+        }
+    };
+    const uint32_t base = (uint32_t)(count / n), extra = (uint32_t)(count % n);
+    uint32_t first = 0;
+    int launch_rc = 0;
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t cnt = base + (k < extra ? 1u : 0u);
+        if (k + 1 == n) {
+            Job::run(k, devs[k], mode, first, cnt, params, ssim, &rcs[k]);          // the calling thread takes the last block
+        } else {
+            try { workers.push_back(std::thread(Job::run, k, devs[k], (int)mode, first, cnt, params, ssim, &rcs[k])); }
+            catch (...) { launch_rc = EAGAIN; break; }
+        }
+        first += cnt;
+    }
+    for (size_t k = 0; k < workers.size(); ++k) workers[k].join();
+    if (launch_rc) return launch_rc;
+    for (size_t k = 0; k < n; ++k)
+        if (rcs[k]) return rcs[k];
+    return 0;
+}
+
 } // extern "C"
 
 namespace {

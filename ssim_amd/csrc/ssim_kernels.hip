@@ -453,52 +453,73 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
 //   (3) a butterfly over the 32 pairs (partner distance 1, 2, 4, 8, 16; fp addition is commutative, so every
 //       lane of the butterfly holds the same bits);
 // and the per-image sum is ssim_reduce_kernel's fixed-order sum of the cells.  The sums are therefore bit-identical
-// however a batch is cut into launches, strips, bands or GPUs.  Strips start on cell boundaries (plan()).
-// Cost: ~80 issue slots per cell and wave (measured: 2.5 % of MODE_EXACT with 8-row cells, hence the taller
-// cells for taller images: 0.6 % at 32 rows); 8 B of HBM per cell.
-// The tree runs on DPP lane permutations (plain VALU moves: no LDS round trip to wait for), each level adding the
-// partner's value so that ALL lanes of the growing group hold the same bits: pairs 1 apart and 2 apart with
-// quad_perm, then -- quads being uniform -- 4 apart is row_half_mirror (lane i <-> 7-i of each 8) and 8 apart is
-// row_mirror (i <-> 15-i of each 16); the 16-lane rows are then combined through v_readlane.
+// however a batch is cut into launches, strips, bands or GPUs.  Strips start on cell boundaries (plan()).  8 B of HBM per cell.
+// Cost (round 3): cells are reduced EIGHT AT A TIME.  Round 2 ran the tree of every cell on its own, as four DPP levels + a
+// readlane level on 64-bit values: ~80 issue slots per cell and wave, 2.4 % of MODE_EXACT on 1080p batches (8-row cells).
+// Now a lane parks its leaf of cell k of the batch in LDS (one ds_write_b64 per cell) and, when eight cells are parked -- or
+// the strip ends --, the wave reduces all of them at once: the batch is 8 cells x 64 leaves = 512 doubles, lane L reads the
+// eight consecutive leaves L*8 .. L*8+7 (one eighth of a 64-leaf tree, or one quarter of a 32-leaf one), adds them as the
+// balanced tree ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7)), and two or three DPP levels combine the lanes that share a tree --
+// the same additions in the same association as the butterfly described above (its level at distance d adds neighbouring
+// blocks of d leaves, and fp addition is commutative), so the cell values, and with them every sum, keep the bits they had:
+// ~35 issue slots per EIGHT cells.  4 KiB of LDS per wave.
+enum { CELL_BATCH = 8 };
+struct CellBatch { double leaf[CELL_BATCH][64]; };
+
 #define SSIM_DPP_ADD(t, CTRL) do {                                                                            \
         const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(t), (CTRL), 0xF, 0xF, false);           \
         const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(t), (CTRL), 0xF, 0xF, false);           \
         (t) += __hiloint2double(hi_, lo_);                                                                    \
     } while (0)
-__device__ __forceinline__ double lane_value(double t, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), lane), __builtin_amdgcn_readlane(__double2loint(t), lane));
-}
-enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_MIRROR = 0x140 };
+enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141 };
 
-// two columns per lane: lanes 0-31 hold cell 2*sx, lanes 32-63 cell 2*sx+1; `pair` = column 2l + column 2l+1
-__device__ __forceinline__ void cell_flush2(const KArgs& args, const Strip& st, uint32_t cell_y, double pair)
+// The eight leaves of this lane's share of the batch, reduced as the balanced tree ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7)),
+// depth first and with the reads kept where they are used (fences): the kernels that run three waves per SIMD have
+// no registers to spare for eight doubles on top of their accumulator rings.
+__device__ __forceinline__ double cell_batch_local(const CellBatch& cb, int lane)
 {
-    double t = pair;
-    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // pairs 1 apart
-    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // 2 apart
-    SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 4 apart
-    SSIM_DPP_ADD(t, DPP_ROW_MIRROR);           // 8 apart: every lane of a 16-lane row holds the row's 16 pairs
-    const double c0 = lane_value(t, 0) + lane_value(t, 16);      // 16 apart
-    const double c1 = lane_value(t, 32) + lane_value(t, 48);
-    if (threadIdx.x == 0) {
-        const uint32_t cx = 2u * st.sx;
-        const gptr_f64 p = (gptr_f64)args.partials + ((size_t)st.img * args.cells_y + cell_y) * args.cells_x + cx;
-        p[0] = c0;
-        if (cx + 1 < args.cells_x) p[1] = c1;
-    }
+    const d2* p = reinterpret_cast<const d2*>(&cb.leaf[0][0]) + 4 * lane;       // leaves lane*8 .. lane*8+7
+    d2 v = p[0];
+    double a = v.x + v.y;
+    __builtin_amdgcn_sched_barrier(0);
+    v = p[1];
+    a = a + (v.x + v.y);
+    __builtin_amdgcn_sched_barrier(0);
+    v = p[2];
+    double b = v.x + v.y;
+    __builtin_amdgcn_sched_barrier(0);
+    v = p[3];
+    b = b + (v.x + v.y);
+    return a + b;
 }
-// one column per lane: the wave is one cell wide; `col` = the lane's column
-__device__ __forceinline__ void cell_flush1(const KArgs& args, const Strip& st, uint32_t cell_y, double col)
+
+// two columns per lane: a leaf is the lane's column pair (column 2l + column 2l+1); leaves 0-31 of a batch row are cell
+// 2*sx, leaves 32-63 cell 2*sx+1.  Four lanes share a 32-leaf tree.  `count` cells of the batch are real.
+__device__ __forceinline__ void cell_batch_flush2(const KArgs& args, const Strip& st, const CellBatch& cb, uint32_t cell_y_first, uint32_t count)
 {
-    double t = col;
-    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // the even/odd column pair
-    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // pairs 1 apart
-    SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 2 apart
-    SSIM_DPP_ADD(t, DPP_ROW_MIRROR);           // 4 apart: a row holds its 8 pairs
-    const double c = (lane_value(t, 0) + lane_value(t, 16)) + (lane_value(t, 32) + lane_value(t, 48));   // 8 apart, 16 apart
-    if (threadIdx.x == 0)
-        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y) * args.cells_x + st.sx] = c;
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));             // everything derived from the lane id below is computed HERE, per flush: hoisted out
+                                               // of the cell loop it would occupy registers next to the accumulator rings
+    double t = cell_batch_local(cb, lane);
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // blocks of 8 leaves -> 16
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // 16 -> 32: the cell
+    const uint32_t c = (uint32_t)lane >> 3, cx = 2u * st.sx + (((uint32_t)lane >> 2) & 1u);
+    if ((lane & 3) == 0 && c < count && cx < args.cells_x)
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + cx] = t;
+}
+// one column per lane: a leaf is the lane's column, the wave is one cell wide.  Eight lanes share a 64-leaf tree
+// (whose first level adds the even/odd column pairs, as the two-column kernel does in registers).
+__device__ __forceinline__ void cell_batch_flush1(const KArgs& args, const Strip& st, const CellBatch& cb, uint32_t cell_y_first, uint32_t count)
+{
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));             // see cell_batch_flush2
+    double t = cell_batch_local(cb, lane);
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR1);            // blocks of 8 leaves -> 16
+    SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // 16 -> 32
+    SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 32 -> 64 (quads are uniform: lane i <-> 7-i of each 8 is a lane of the other quad)
+    const uint32_t c = (uint32_t)lane >> 3;
+    if ((lane & 7) == 0 && c < count)
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + st.sx] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -551,6 +572,7 @@ void ssim_strip2_kernel(const KArgs args)
     static_assert(MODE != MODE_DOUBLE, "fp64 mode uses ssim_strip1_kernel");
 
     __shared__ __attribute__((aligned(16))) Slot2 ring[2];
+    __shared__ __attribute__((aligned(16))) CellBatch cells;
 
     const int lane = threadIdx.x;
     // the separable taps as six scalars (an array inside the kernel argument block, passed on by reference, can end up
@@ -829,9 +851,9 @@ void ssim_strip2_kernel(const KArgs args)
     }
     // Main rows, one reduction cell at a time; only the image's last cell can be shorter.
     const int cell_rows = 1 << args.cell_shift;
-    uint32_t cell_y = (uint32_t)y0 >> args.cell_shift;
+    uint32_t cell_y = (uint32_t)y0 >> args.cell_shift, parked = 0;
 #pragma unroll 1
-    for (int left = y_end - y0; left > 0; left -= cell_rows, ++cell_y) {
+    for (int left = y_end - y0; left > 0; left -= cell_rows) {
         const int rows = left < cell_rows ? left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
@@ -840,8 +862,19 @@ void ssim_strip2_kernel(const KArgs args)
         }
         if (rows & 1)
             row(r, S0(), std::integral_constant<int, ROW_LAST>());
-        cell_flush2(args, st, cell_y, (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0));
+        cells.leaf[parked][lane] = (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0);      // this cell's leaf of the lane
         colsum[0] = colsum[1] = 0.0;
+        if (++parked == CELL_BATCH) {
+            wave_sync();
+            cell_batch_flush2(args, st, cells, cell_y, parked);
+            wave_sync();
+            cell_y += parked;
+            parked = 0;
+        }
+    }
+    if (parked) {
+        wave_sync();
+        cell_batch_flush2(args, st, cells, cell_y, parked);
     }
 }
 
@@ -880,6 +913,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     typedef typename std::conditional<DBL, double, float>::type XV;  // ab stream
 
     __shared__ __attribute__((aligned(16))) Slot1 ring[2];
+    __shared__ __attribute__((aligned(16))) CellBatch cells;
 
     const int lane = threadIdx.x;
     const Strip st = strip_setup(args, Slot1::STRIP_W);
@@ -1039,9 +1073,9 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
     }
     const int cell_rows = 1 << args.cell_shift;
-    uint32_t cell_y = (uint32_t)(y0 >> args.cell_shift);
+    uint32_t cell_y = (uint32_t)(y0 >> args.cell_shift), parked = 0;
 #pragma unroll 1
-    for (int64_t left = y_end - y0; left > 0; left -= cell_rows, ++cell_y) {
+    for (int64_t left = y_end - y0; left > 0; left -= cell_rows) {
         const int rows = left < cell_rows ? (int)left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
@@ -1050,8 +1084,19 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         }
         if (rows & 1)
             row(r, S0(), std::integral_constant<int, ROW_LAST>());
-        cell_flush1(args, st, cell_y, col_ok ? colsum : 0.0);
+        cells.leaf[parked][lane] = col_ok ? colsum : 0.0;
         colsum = 0.0;
+        if (++parked == CELL_BATCH) {
+            wave_sync();
+            cell_batch_flush1(args, st, cells, cell_y, parked);
+            wave_sync();
+            cell_y += parked;
+            parked = 0;
+        }
+    }
+    if (parked) {
+        wave_sync();
+        cell_batch_flush1(args, st, cells, cell_y, parked);
     }
 }
 

@@ -559,3 +559,63 @@ def test_pipelined_host_batch_equals_single_host_calls(oracle):
     out2 = (ctypes.c_float * 2)()
     assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 2, p2, out2) == errno.EINVAL
     assert lib.rmgr_ssim_hip_compute_ssim_batch_host(None, 0, None, None) == 0
+
+
+def test_one_process_several_devices_batch(oracle):
+    """rmgr_ssim_hip_compute_ssim_batch_host_devices ('one process x 8 devices'): the batch sharded by
+    image over a device list, one worker thread + context per entry.  Every list -- all visible devices, one device, the
+    same device three times (three contexts on one GPU: what a 1-GPU box can exercise), more entries than pairs -- must
+    return the single-device floats bit for bit, in every arithmetic mode; uneven splits included."""
+    rng = np.random.default_rng(4242)
+    ndev = ssim_amd.device_count()
+    for (h, w, n) in [(96, 130, 37), (720, 1280, 11), (8, 8, 2)]:
+        ps = []
+        for i in range(n):
+            a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            ps.append((a, np.clip(a.astype(np.int32) + rng.integers(-35, 36, (h, w)), 0, 255).astype(np.uint8)))
+        want = ssim_amd.compute_ssim_batch(ps)                       # default context, MODE_EXACT
+        ov = oracle.ssim_f32(ps[0][0], ps[0][1])[0]
+        assert f32_hex(want[0]) == f32_hex(ov)
+        for devices in (None, [0], [0, 0, 0], [ndev - 1] * 5, list(range(ndev)) * 2):
+            got = ssim_amd.compute_ssim_batch_devices(ps, devices)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (h, w, n, devices)
+    ps = ps[:2] + [(np.ascontiguousarray(ps[0][0][::-1]), ps[0][1])]
+    for mode in (ssim_amd.MODE_UNFUSED, ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE, ssim_amd.MODE_DOUBLE):
+        with ssim_amd.Context(0, mode=mode) as ctx:
+            want = ssim_amd.compute_ssim_batch(ps, ctx)
+        got = ssim_amd.compute_ssim_batch_devices(ps, [0, 0], mode)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), mode
+    # argument checks
+    lib = ssim_amd.load_library()
+    a = np.zeros((8, 8), np.uint8)
+    p = (ssim_amd.Params * 1)(ssim_amd.make_params(8, 8, a.ctypes.data, 1, 8, a.ctypes.data, 1, 8))
+    out = (ctypes.c_float * 1)()
+    bad = (ctypes.c_int32 * 1)(ndev)
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host_devices(bad, 1, 0, 1, p, out) == errno.EINVAL          # not a visible device
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host_devices(bad, 0, 0, 1, p, out) == errno.EINVAL          # a list of length 0
+    assert lib.rmgr_ssim_hip_compute_ssim_batch_host_devices(None, 0, 0, 0, None, None) == 0
+
+
+def test_context_on_another_device_than_the_current_one():
+    """an entry point must keep the CONTEXT's device current for its whole duration -- the multi-channel and
+    luminance host calls allocate, create events and launch after their staging helper returns.  Needs two GPUs (the
+    driver's multi-GPU boxes); on one GPU the guard's scope is covered by construction only."""
+    if ssim_amd.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: a context on device 1 while device 0 is current")
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8)
+    want, want_map = ssim_amd.compute_ssim_channels(a, b, want_map=True)          # default context: device 0
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); import ssim_amd; rng = np.random.default_rng(3); "
+            "a = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8); b = np.clip(a.astype(np.int32) + rng.integers(-20, 21, a.shape), 0, 255).astype(np.uint8); "
+            "v, m = ssim_amd.compute_ssim_channels(a, b, want_map=True); y, _ = ssim_amd.compute_ssim_luminance(a, b); "
+            "print(' '.join('%%08x' %% int(x) for x in v.view(np.uint32)), '%%08x' %% int(np.float32(y).view(np.uint32)))"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = []
+    for dev in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, RMGR_SSIM_HIP_DEVICE=dev))
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(r.stdout.split())
+    assert outs[0] == outs[1] and outs[0][:3] == ["%08x" % int(x) for x in want.view(np.uint32)]

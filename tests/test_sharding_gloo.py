@@ -86,6 +86,35 @@ def test_bench_builds_its_own_rank_launcher():
     assert cmd[cmd.index(bench) + 1:] == ["--gpus", "4", "--steps", "3", "--scaling", "strong", "--workload", "1080p"]
 
 
+def test_bench_shard_tables_are_what_design_section_6_says():
+    """The sharding the timed run uses (`bench.py --print-shards`, the same function the ranks call): BASELINE.json configs[3]
+    -- 1024 x 1080p over 8 GPUs, strong scaling -- is eight contiguous blocks of 128 pairs; the default workload is weak
+    scaling, 32 pairs of 4096^2 per GPU; a batch that does not divide gives the first ranks one extra pair.  Plus the
+    2-rank launcher line of the same configuration."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+
+    def run(*argv):
+        r = subprocess.run([sys.executable, bench] + list(argv), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-500:]
+        return r.stdout
+
+    t = json.loads(run("--gpus", "8", "--scaling", "strong", "--workload", "1080p", "--print-shards"))
+    assert t == {"scaling": "strong", "total": 1024, "shards": [[128 * r, 128 * (r + 1)] for r in range(8)]}
+    t = json.loads(run("--gpus", "8", "--print-shards"))
+    assert t == {"scaling": "weak", "total": 256, "shards": [[32 * r, 32 * (r + 1)] for r in range(8)]}
+    t = json.loads(run("--gpus", "3", "--scaling", "strong", "--workload", "1080p", "--pairs", "10", "--print-shards"))
+    assert t["shards"] == [[0, 4], [4, 7], [7, 10]]
+    for n in (1, 2, 4, 8):                                  # every pair has exactly one owner, in order, for every N the driver runs
+        t = json.loads(run("--gpus", str(n), "--scaling", "strong", "--workload", "1080p", "--print-shards"))
+        flat = [i for a, b in t["shards"] for i in range(a, b)]
+        assert flat == list(range(1024)) and len(t["shards"]) == n
+    cmd = run("--gpus", "2", "--scaling", "strong", "--workload", "1080p", "--print-launch").split()
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index(bench) + 1:] == ["--gpus", "2", "--scaling", "strong", "--workload", "1080p"]
+
+
 def test_bench_two_ranks_fail_only_at_the_missing_device():
     """On a box without GPUs the self-launched 2-rank run must get as far as every rank looking for its device."""
     import subprocess
