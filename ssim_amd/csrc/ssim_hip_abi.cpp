@@ -376,8 +376,12 @@ void rows_extent(const rmgr_ssim_ImgParams& im, uint32_t w, uint32_t r0, uint32_
     hi = std::max(ya, yb) + (dx > 0 ? dx : 0);
 }
 
-// The banded pipeline of one large host pair with a map (see the call site).  `dev`/`d` address the staged device
-// copies (not yet filled), loA/loB are the byte offsets of the images' lowest addresses relative to topLeft.
+// The banded pipeline of one large host pair (see the call site), with or without a map.  `dev`/`d` address the staged
+// device copies (not yet filled), loA/loB are the byte offsets of the images' lowest addresses relative to topLeft.
+// Without a map there is nothing to send back and no helper thread: the bands only hide the kernel behind the H2D copy
+// of the following band.  Measured (round 3, profiles/r03_host_probe.txt): every additional pageable copy costs ~20 us,
+// more than the ~12 us of kernel a band hides at 4096^2 (0.742 ms unbanded, 0.762 / 0.790 / 0.891 ms at 2 / 4 / 8 bands);
+// it pays from 8192^2 on (2.795 -> 2.650 ms at 4 bands), so only such images take this path without a map.
 int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rmgr_ssim_Params& dev, const PairDesc& d, int64_t loA, int64_t loB)
 {
     (void)dev;
@@ -385,6 +389,7 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
     // Band size: ~2 Mpixel (8 MB of map) per band, at most kMaxBands -- measured on MI355X / PCIe Gen5 (profiles/
     // r02_host_probe.txt): 4096^2 10.6 Gpix/s at 6-8 bands (8.2 unpipelined), 8192^2 12.0 at 16 (8.7), 2048^2 8.1 at 2 (7.0).
     int bands = (int)std::min<uint64_t>(((uint64_t)W * H + (1u << 21) - 1) >> 21, rmgr_ssim_hip_Context_::kMaxBands);
+    if (!p.ssimMap) bands = std::min(bands, 4);
     if (const char* e = getenv("RMGR_SSIM_HIP_BANDS")) bands = atoi(e);
     bands = std::max(1, std::min<int>(bands, rmgr_ssim_hip_Context_::kMaxBands));
     const uint32_t cell = ssim_hip::cell_rows_for(H);         // windows start on reduction-cell boundaries
@@ -432,9 +437,10 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
         }
     };
     const Worker work = {c, &p, &sh, out, n};
+    const bool with_map = p.ssimMap != NULL;
     std::thread helper;
-    bool threaded = true;
-    try { helper = std::thread(work); } catch (...) { threaded = false; }
+    bool threaded = with_map;
+    if (with_map) { try { helper = std::thread(work); } catch (...) { threaded = false; } }
 
     int rc = 0;
     const rmgr_ssim_ImgParams* img[2] = {&p.imgA, &p.imgB};
@@ -451,7 +457,7 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
         if (!rc && e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->band_copied[k], 0);
         if (!rc && e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
         if (!rc && out[k + 1] > out[k])
-            rc = enqueue(c, W, H, 1, &d, true, c->h_sums, out[k], out[k + 1] - out[k], k == n - 1);
+            rc = enqueue(c, W, H, 1, &d, with_map, c->h_sums, out[k], out[k + 1] - out[k], k == n - 1);
         if (!rc) {
             e = hipEventRecord(c->band_done[k], c->stream);
             if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
@@ -466,7 +472,7 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
         sh.cv.notify_one();
     }
     if (threaded) helper.join();
-    else if (!rc) work();                         // no thread could be started: the same steps, serially
+    else if (!rc && with_map) work();             // no thread could be started: the same steps, serially
     const hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { (void)hipGetLastError(); if (!rc) rc = map_hip_error(e); }
     (void)hipStreamSynchronize(c->copy_stream);
@@ -869,7 +875,8 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     // while band k is computed (a row window of the same launch geometry; the cell-based reduction makes the sum
     // bit-identical to the one-launch result) and band k-1's map rows travel back, written by a helper thread
     // straight into the caller's buffer.
-    if (!staged && params->ssimMap && bandable(*params)) {
+    // Without a map a few bands hide the kernel behind the copy, which pays only for very large images (compute_banded()).
+    if (!staged && bandable(*params) && (params->ssimMap || (uint64_t)W * H >= (uint64_t(1) << 26))) {
         if ((rc = compute_banded(c, *params, dev, d, loA, loB))) return rc;
     } else {
         if (!staged) {

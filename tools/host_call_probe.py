@@ -32,8 +32,13 @@ def main():
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
         return min(ts), sorted(ts)[len(ts) // 2]
 
+    os.environ.pop("RMGR_SSIM_HIP_BANDS", None)
     best, med = timed(lambda: ssim_amd.compute_ssim(a, b))
-    print("%dx%d no map: best %.3f ms (%.1f Gpix/s), median %.3f ms" % (size, size, best * 1e3, px / best / 1e9, med * 1e3))
+    print("%dx%d no map, default bands: best %.3f ms (%.1f Gpix/s), median %.3f ms" % (size, size, best * 1e3, px / best / 1e9, med * 1e3))
+    for nb in bands:
+        os.environ["RMGR_SSIM_HIP_BANDS"] = str(nb)
+        best, med = timed(lambda: ssim_amd.compute_ssim(a, b))
+        print("%dx%d no map, %2d bands: best %.3f ms (%.2f Gpix/s), median %.3f ms (%.2f Gpix/s)" % (size, size, nb, best * 1e3, px / best / 1e9, med * 1e3, px / med / 1e9))
     for nb in bands:
         os.environ["RMGR_SSIM_HIP_BANDS"] = str(nb)
         best, med = timed(lambda: ssim_amd.compute_ssim(a, b, out_map=m))
