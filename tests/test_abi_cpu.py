@@ -388,6 +388,11 @@ def test_reference_naive_header_compiles_against_this_header(tmp_path):
                   "double probe(const rmgr::ssim::GeneralParams& p, double* map)\n"
                   "{ return rmgr::ssim::naive::compute_ssim<double, rmgr::ssim::uint8_t>(p.width, p.height, p.imgA.topLeft, p.imgA.step, p.imgA.stride,\n"
                   "      p.imgB.topLeft, p.imgB.step, p.imgB.stride, map, 1, p.width); }\n")
+    # the reference's OpenMP adapter (src/ssim-openmp.c: includes <rmgr/ssim-openmp.h>, builds a rmgr_ssim_ThreadPool and calls
+    # rmgr_ssim_compute_ssim) is the one reference-side CALLER that needs no un-vendored dependency: it must compile unchanged
+    r = subprocess.run(["gcc", "-std=c99", "-fopenmp", "-fsyntax-only", "-Wall", "-Werror", "-I" + INCLUDE, "/root/reference/src/ssim-openmp.c"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     for std in ("gnu++98", "gnu++17"):      # the __float128 literals of ssim_naive.h:72 need the GNU dialect, with the reference header too
         r = subprocess.run(["g++", "-std=" + std, "-D_USE_MATH_DEFINES", "-fsyntax-only", "-Wall", "-I" + INCLUDE, "-I/root/reference/tests", str(tu)],
                            capture_output=True, text=True)

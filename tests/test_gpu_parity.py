@@ -468,10 +468,12 @@ def test_native_rccl_exchange_single_rank():
 @pytest.mark.parametrize("openmp", [False, True])
 @pytest.mark.parametrize("heap", [False, True])
 @pytest.mark.parametrize("want_map", [False, True])
-def test_reference_test_matrix_on_host_entry_points(manifest, openmp, heap, want_map):
+def test_reference_test_matrix_on_host_entry_points(manifest, refsets, openmp, heap, want_map):
     """The reference's own test matrix (tests/rmgr-ssim-tests.cpp:468-507): {stack, heap} x {map, nomap} x
-    {serial, openmp} over every image set, here through the unchanged host-pointer entry points.  Where the
+    {serial, openmp} over EVERY image set of the reference's tests (:520-524: einstein, bbb360, bbb1080, bbb255, bbb257 --
+    11 JPEG qualities x 3 channels each), here through the unchanged host-pointer entry points.  Where the
     reference allows 2e-6 / 1e-3 against its naive oracle, the GPU path must match the FMA reference exactly."""
+    from conftest import refset_pair
     for name in image_entries(manifest):
         ent = manifest[name]
         a, b = load_pair(ent)
@@ -479,6 +481,17 @@ def test_reference_test_matrix_on_host_entry_points(manifest, openmp, heap, want
         assert f32_hex(v) == ent["fma"]["ssim_hex"], name
         if want_map:
             assert sha(m) == ent["fma"]["map_sha256"], name
+    n = 0
+    for set_name in ("bbb255", "bbb257", "bbb360", "bbb1080"):
+        for key in sorted(refsets[set_name]["pairs"]):
+            ent = refsets[set_name]["pairs"][key]
+            a, b = refset_pair(ent)
+            v, m = ssim_amd.compute_ssim(a, b, want_map=want_map, openmp=openmp, allocator=heap)
+            assert f32_hex(v) == ent["fma"]["ssim_hex"], (set_name, key)
+            if want_map:
+                assert sha(m) == ent["fma"]["map_sha256"], (set_name, key)
+            n += 1
+    assert n == 132
 
 
 def test_dropin_call_is_thread_safe(manifest):

@@ -22,7 +22,7 @@ pmc() {   # name, counters, target args...
   local name=$1 ctrs=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
 }
-for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
+for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
   set -- $cfg; tag=$1; shift
   pmc ${tag}_fetch FETCH_SIZE "$@"
   pmc ${tag}_write WRITE_SIZE "$@"
@@ -31,9 +31,9 @@ for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920
 done
 # kernel-only speeds per mode (HIP events, tools/ab.py): batch of 8, single pair, with map
 {
-  for m in 0 3 1 2; do timeout 300 python3 tools/ab.py 8 4096 $m 0 0 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode $m:/"; done
-  for m in 0 1 2; do timeout 300 python3 tools/ab.py 1 4096 $m 0 0 3 0 | tail -1 | sed "s/^/1 x 4096^2 mode $m:/"; done
-  for m in 0 1 2; do timeout 300 python3 tools/ab.py 2 8192 $m 0 0 3 1 | tail -1 | sed "s/^/2 x 8192^2 + map mode $m:/"; done
+  for m in 0 3 1 4 2; do timeout 300 python3 tools/ab.py 8 4096 $m 0 0 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode $m:/"; done
+  for m in 0 1 4 2; do timeout 300 python3 tools/ab.py 1 4096 $m 0 0 3 0 | tail -1 | sed "s/^/1 x 4096^2 mode $m:/"; done
+  for m in 0 1 4 2; do timeout 300 python3 tools/ab.py 2 8192 $m 0 0 3 1 | tail -1 | sed "s/^/2 x 8192^2 + map mode $m:/"; done
   timeout 300 python3 tools/ab.py 8 4096 0 0 1 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode 0 one-column kernel:/"
 } > "$OUT/mode_speeds.txt" 2>&1
 timeout 900 python3 tests/tools/error_table.py > "$OUT/error_table.md" 2> "$OUT/error_table.err"

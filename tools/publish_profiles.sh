@@ -4,13 +4,14 @@
 set -e
 cd "$(dirname "$0")/.."
 P=$1
-R=${2:-r02}
+R=${2:-r03}
 note="-- PMC passes (one rocprofv3 run per counter set). FETCH_SIZE is KiB and reads 1/2 of the true bytes (profiles/r01_fetch_size_calibration.md)"
 pmc() { python3 tools/summarize_prof.py "round ${R#r0}, final kernel: tools/profile_target.py $2 $note" $P/$1_fetch/t_kernel_trace.csv $P/$1_fetch/t_counter_collection.csv $P/$1_write/t_counter_collection.csv $P/$1_sq/t_counter_collection.csv $P/$1_sq2/t_counter_collection.csv > profiles/$3; }
 pmc 4k     "8 x 4096^2 (no map), MODE_EXACT"        ${R}_final_exact_4k_pmc.md
 pmc 8kmap  "2 x 8192^2 with map, MODE_EXACT"        ${R}_final_exact_8k_map_pmc.md
 pmc 1080p  "32 x 1920x1080 (no map), MODE_EXACT"    ${R}_final_exact_1080p_pmc.md
-pmc 4kfast "8 x 4096^2 (no map), MODE_FAST"         ${R}_final_fast_4k_pmc.md
+pmc 4kfast "8 x 4096^2 (no map), MODE_FAST (reference-order E planes, separable mu)" ${R}_final_fast_4k_pmc.md
+[ -d $P/4ksep_sq ] && pmc 4ksep "8 x 4096^2 (no map), MODE_SEPARABLE" ${R}_final_separable_4k_pmc.md
 [ -d $P/4kdouble_sq ] && pmc 4kdouble "4 x 4096^2 with map, MODE_DOUBLE (ssim_strip1_kernel<2,true>)" ${R}_final_double_4k_map_pmc.md
 cp $P/bench_4k.json profiles/${R}_final_bench.json
 cp $P/bench_8k-map.json profiles/${R}_final_bench_8k_map.json
