@@ -367,3 +367,50 @@ def test_cli_png_versus_jpeg_on_gpu(tmp_path, manifest, oracle):
     ov = oracle.ssim_f32(bt601(a), bt601(j))[0]
     r = run("-y", pa, pj)
     assert r.returncode == 0 and r.stdout == "% 7.4f\n" % ov
+
+
+def test_own_decoders_reproduce_the_fixture_pixels_of_every_reference_image(tmp_path, refsets):
+    """Every image file of the reference's bbb sets (tests/golden/images: 2 PNG frames + 22 progressive JPEGs) through the
+    tool's own PNG / JPEG readers: the decoded planes hash to the values recorded when the expected outputs were generated
+    (refsets.json: PIL / libjpeg decode), i.e. the tool sees exactly the pixels the parity fixtures are defined on."""
+    import hashlib
+    seen = {}
+    for set_name in ("bbb360", "bbb1080"):
+        for key, ent in sorted(refsets[set_name]["pairs"].items()):
+            for f, h in ((ent["a_file"], ent["a_sha256"]), (ent["b_file"], ent["b_sha256"])):
+                if f not in seen:
+                    seen[f] = decode_with_cli(tmp_path, os.path.join(GOLDEN, "images", f))
+                    assert seen[f].shape == (ent["height"], ent["width"], 3), f
+                plane = np.ascontiguousarray(seen[f][:, :, ent["channel"]])
+                assert hashlib.sha256(plane.tobytes()).hexdigest() == h, (f, ent["channel"])
+    assert len(seen) == 24
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", ["360", "1080"])
+def test_cli_on_the_reference_image_files(tmp_path, refsets, res):
+    """`rmgr-ssim frame.png frame_qNN.jpg [map.pfm]` on the reference's own files, end to end (own decoders -> all channels in
+    one launch -> the reference's printf formats): the three channel lines and the average are the FMA path's values
+    (refsets.json), the PFM map its per-pixel values."""
+    import hashlib
+    pairs = refsets["bbb" + res]["pairs"]
+    png = os.path.join(GOLDEN, "images", "big_buck_bunny_%s_07806.png" % res)
+    for q in ("00", "50", "100") if res == "1080" else ("00", "10", "20", "30", "40", "50", "60", "70", "80", "90", "100"):
+        jpg = os.path.join(GOLDEN, "images", "big_buck_bunny_%s_07806_%s.jpg" % (res, q))
+        want = [np.array([int(pairs["q%s_ch%d" % (q, c)]["fma"]["ssim_hex"], 16)], np.uint32).view(np.float32)[0] for c in range(3)]
+        with_map = q == "50"
+        pfm = str(tmp_path / "m.pfm")
+        r = run(png, jpg, pfm) if with_map else run(png, jpg)
+        assert r.returncode == 0, r.stderr
+        avg = np.float32(0)
+        for v in want:
+            avg = np.float32(avg + v)
+        assert r.stdout.splitlines() == ["Channel %u: % 7.4f" % (c, want[c]) for c in range(3)] + ["Average  : % 7.4f" % (avg / np.float32(3))], (res, q)
+        if with_map:
+            e = pairs["q50_ch0"]
+            raw = open(pfm, "rb").read()
+            header = b"PF\n%d %d\n-1.0\n" % (e["width"], e["height"])
+            assert raw.startswith(header)
+            m = np.frombuffer(raw[len(header):], np.float32).reshape(e["height"], e["width"], 3)[::-1]
+            for c in range(3):
+                assert hashlib.sha256(np.ascontiguousarray(m[:, :, c]).tobytes()).hexdigest() == pairs["q50_ch%d" % c]["fma"]["map_sha256"], (res, c)

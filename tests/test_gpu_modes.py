@@ -71,6 +71,50 @@ def test_fast_modes_full_size_4k(gpu_ctx, oracle, mode):
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
 
 
+@pytest.mark.parametrize("mode", [ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE])
+def test_fast_modes_reproduce_the_cpu_model_of_their_arithmetic(gpu_ctx, oracle, mode):
+    """tests/tools/fast_mode_model.py restates both modes' arithmetic in numpy (that model is what DESIGN.md's tables and
+    margins come from).  The kernels -- both variants -- must produce the model's per-pixel bits: on noise, on natural
+    fixtures, and on the division's corner statistics (anti-correlated textures whose covariance sweeps 2*sAB + c2 through
+    zero, flat, saturated and maximal-contrast images: the in-range division of the packed epilogues against numpy's IEEE
+    one).  The model emulates fma through float64, which double-rounds once in ~1e8 operations: at most 3 pixels per image
+    may differ, by one ulp."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fast_mode_model as model
+    fn = model.mode_fast if mode == ssim_amd.MODE_FAST else model.mode_separable
+    rng = np.random.default_rng(99)
+    cases = []
+    for (h, w) in ((1, 1), (7, 300), (64, 128), (65, 257), (200, 333)):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        cases.append((a, np.clip(a.astype(np.int32) + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8)))
+    h, w = 120, 640
+    xx = np.arange(w)[None, :].repeat(h, 0)
+    for kk in (1.0, 0.5, 2.0):
+        amp = xx / w * (12.0 / np.sqrt(kk))
+        t = rng.choice([-1.0, 1.0], (h, w))
+        base = int(rng.integers(60, 196))
+        cases.append((np.clip(np.rint(base + amp * t), 0, 255).astype(np.uint8), np.clip(np.rint(base - kk * amp * t), 0, 255).astype(np.uint8)))
+    cases += [(np.zeros((40, 300), np.uint8), np.full((40, 300), 255, np.uint8)), (np.full((40, 300), 255, np.uint8), np.full((40, 300), 255, np.uint8)),
+              (rng.choice([0, 255], (90, 400)).astype(np.uint8), rng.choice([0, 255], (90, 400)).astype(np.uint8)),
+              ((np.indices((64, 256)).sum(0) % 2 * 255).astype(np.uint8), (255 - np.indices((64, 256)).sum(0) % 2 * 255).astype(np.uint8))]
+    cases.append(oracle.synth_pair(700, 300, 0x5EED + 9))
+    gpu_ctx.set_mode(mode)
+    try:
+        for variant in (0, 1):
+            gpu_ctx.set_tuning(0, variant)
+            for i, (a, b) in enumerate(cases):
+                want = fn(a, b)
+                v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+                ulps = np.abs(m.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+                assert int((ulps != 0).sum()) <= 3 and int(ulps.max()) <= 1, (mode, variant, i, int((ulps != 0).sum()), int(ulps.max()))
+                g = np.float32(want.astype(np.float64).sum() / np.float64(want.size))
+                assert abs(float(v) - float(g)) <= 1.3e-7, (mode, variant, i)
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+
+
 def test_double_mode_vs_naive_oracle(gpu_ctx, manifest, oracle):
     gpu_ctx.set_mode(ssim_amd.MODE_DOUBLE)
     try:
