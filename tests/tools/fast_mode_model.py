@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """CPU model (numpy) of the arithmetic of the two non-bit-exact fp32 modes of ssim_kernels.hip, and the study that chose
-them, over ALL of the reference's test image sets (einstein, bbb255, bbb257, bbb360, bbb1080: 150 pairs).
+them, over ALL of the reference's test image sets (einstein, bbb255, bbb257, bbb360, bbb1080: 138 pairs).
 
   MODE_FAST       the three E[.] planes in the reference FMA path's exact operation order (blur_exact: bit-identical to
                   the reference's planes), the two mu planes separable (blur_separable_pair, centre-first row pass, fused
@@ -21,7 +21,7 @@ What the study shows (DESIGN.md section 2 has the table):
   * almost all of the reference's per-pixel error is the rounding of its three E[.] planes (reference mu + exact E:
     6.5e-4 from the reference; exact mu + reference E: 2.2e-4), while its global bias sits in the mu planes on some images
     and in the E planes on others.  Reproducing the E planes bit for bit and approximating only the mu planes (MODE_FAST)
-    stays within 2.3e-4 per pixel / 1.02e-6 global of the FMA reference on all 150 pairs.
+    stays within 2.3e-4 per pixel / 1.02e-6 global of the FMA reference on all 138 pairs.
 
 Reference values come from the oracle's C restatement (bit-identical to the real reference kernels on every one of these
 pairs: tests/test_oracle_golden.py), so the tool runs wherever the repository does; maps are cached under /tmp.
