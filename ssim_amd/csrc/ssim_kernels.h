@@ -67,11 +67,11 @@ inline int interleaved_group(const PairDesc* d, uint32_t count)
 // Strip geometry the launcher will use for (mode, variant, requested rows; 0 = default).
 // The library default (tuning variant 0) is the two-column kernel, except for launches too small to give even a
 // quarter of the SIMDs a strip at the minimum strip height: there the one-column kernel's twice-as-many, half-as-wide
-// strips finish sooner (one 256^2 or 512^2 pair, bit-exact modes: 19.3 -> 15.4 us; equal from 1024^2 on; MODE_FAST
-// gains nothing).  Results do not depend on the choice (the cell reduction is common to both kernels).
+// strips finish sooner (one 256^2 or 512^2 pair, bit-exact modes and the hybrid: 19.3 -> 15.4 us; equal from 1024^2 on;
+// the three-wave kernels gain nothing).  Results do not depend on the choice (the cell reduction is common to both kernels).
 inline int default_variant(uint32_t width, uint32_t height, uint32_t count, int mode, int cu_count)
 {
-    if (mode != MODE_EXACT && mode != MODE_UNFUSED) return 0;
+    if (mode != MODE_EXACT && mode != MODE_UNFUSED && mode != MODE_FAST) return 0;     // the two-waves-per-SIMD kernels
     const uint64_t strips = (uint64_t)((width + 127) / 128) * ((height + 7) / 8) * count;
     return strips <= (uint64_t)(cu_count > 0 ? cu_count : 256) ? 1 : 0;      // fewer strips than CUs (a quarter of the SIMDs)
 }
