@@ -3,6 +3,7 @@
 #   make            -> ssim_amd/lib/librmgr-ssim-hip.so  + oracle libs
 #   make lib        -> the product library only
 #   make oracle     -> oracle/libssim_oracle.so (+ oracle/_ref when /root/reference exists)
+#   make sanitize   -> CPU-only ASan/UBSan pass over the tool's codecs and the oracle
 HIPCC   ?= /opt/rocm/bin/hipcc
 CXX     ?= g++
 ARCH    ?= gfx950
@@ -73,8 +74,18 @@ install: lib
 	install -m 755 $(BIN)/rmgr-ssim $(DESTDIR)$(PREFIX)/bin/
 	printf 'prefix=%s\nlibdir=$${prefix}/lib\nincludedir=$${prefix}/include\n\nName: rmgr-ssim\nDescription: SSIM (rmgr::ssim API) on AMD MI355X / gfx950\nVersion: 2.1.0\nLibs: -L$${libdir} -lrmgr-ssim-hip\nCflags: -I$${includedir}\n' '$(PREFIX)' > $(DESTDIR)$(PREFIX)/lib/pkgconfig/rmgr-ssim.pc
 
+# CPU-only sanitizer pass (GPU ASan is not available on this pool): the command-line tool's own PNG / JPEG / PNM / BMP / TGA
+# readers and writers against valid, odd and mutated files (tests/test_cli.py, no GPU needed for --decode), and the oracle's
+# C restatement, both built with -fsanitize=address,undefined.
+sanitize: lib oracle
+	@mkdir -p build/sanitize
+	$(CXX) -std=c++98 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -Wextra -Iinclude $(SRC)/ssim_cli.cpp -o build/sanitize/rmgr-ssim-asan -L$(OUT) -lrmgr-ssim-hip -Wl,-rpath,$(abspath $(OUT))
+	ASAN_OPTIONS=detect_leaks=0 RMGR_SSIM_CLI=$(abspath build/sanitize/rmgr-ssim-asan) python3 -m pytest tests/test_cli.py -x -q -m "not gpu"
+	$(CC) -O1 -g -std=c99 -D_GNU_SOURCE -ffp-contract=off -fno-math-errno -fopenmp -mavx2 -mfma -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -shared -fPIC -o build/sanitize/libssim_oracle_asan.so oracle/ssim_oracle.c -lm
+	LD_PRELOAD=$$($(CC) -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python3 tests/tools/sanitize_oracle.py $(abspath build/sanitize/libssim_oracle_asan.so) $(abspath .)
+
 clean:
 	rm -rf build $(OUT) $(BIN)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle clean install
+.PHONY: all lib oracle clean install sanitize

@@ -14,7 +14,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, f32_hex
 
-CLI = os.path.join(ROOT, "ssim_amd", "bin", "rmgr-ssim")
+CLI = os.environ.get("RMGR_SSIM_CLI") or os.path.join(ROOT, "ssim_amd", "bin", "rmgr-ssim")     # RMGR_SSIM_CLI: e.g. an ASan/UBSan build of the tool
 
 
 def run(*args):
