@@ -55,11 +55,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH
 # VALU work per output pixel, lane-ops: exact = 5 planes x (5 fold adds + 6 mul + 30 fma + 10 ring adds) = 255
 # + 23 for the SSIM formula / divide / fp64 accumulate; fast (hybrid) = 3 reference-order planes x 51 + 2 separable planes
 # x 22 + 23; separable = 4 planes x 22 + 23 + 8 (a^2 + b^2 is blurred as one plane; centring and the restored mu);
-# fp64 mode: VALU ISSUE SLOTS per pixel counted in the compiled hot loop (tools/isa_mix.py: 294 VALU instructions per two
+# fp64 mode: VALU ISSUE SLOTS per pixel counted in the compiled hot loop (tools/isa_mix.py: 279 VALU instructions per two
 # rows of one pixel per lane) -- 88 fp64 multiply-adds of the blur and the formula, 25 fp32->fp64 conversions of the folded
-# sums, 10 packed fold adds, 24 of staging / addressing / in-range division / map value; every non-packed instruction
+# sums, 10 packed fold adds, 17 of staging / in-range division / map value; every non-packed instruction
 # occupies one fp64-rate slot, which is what the 39.3 T/s peak counts (round 2 counted the 88 blur operations only)
-VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 147, 3: 278, 4: 119}
+VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 140, 3: 278, 4: 119}
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
@@ -214,7 +214,7 @@ def kernel_name(mode, variant, want_map):
     """Template instance rocprofv3 lists for this configuration (ssim_kernels.hip): the two-column kernel's second argument
     is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even); the one-column kernel's is a bool."""
     if mode == 2 or variant == 1:
-        return "ssim_strip1_kernel<%d, %s>" % (mode, "true" if want_map else "false")
+        return "ssim_strip1_kernel<%d, %s, false>" % (mode, "true" if want_map else "false")     # last argument: 64-bit addressing (never needed by the bench's pairs)
     return "ssim_strip2_kernel<%d, %d>" % (mode, 2 if want_map else 0)
 
 

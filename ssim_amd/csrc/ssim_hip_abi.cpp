@@ -248,9 +248,12 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
 {
     int variant = c->variant;
     if (variant == 0 && c->strip_rows == 0) variant = ssim_hip::default_variant(width, height, count, c->mode, c->cu_count);
-    for (uint32_t i = 0; i < count && variant != 1; ++i)
-        if (!ssim_hip::fits_strip2(descs[i], width, height)) variant = 1;
+    bool all_fit = true;
+    for (uint32_t i = 0; i < count && all_fit; ++i)
+        all_fit = ssim_hip::fits_strip2(descs[i], width, height);
+    if (!all_fit) variant = 1;
     ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
+    geo.wide = !all_fit;                             // the 64-bit form of the one-column kernel only where it is needed
     geo.map_unit = any_map && (width & 1u) == 0;     // the 8-byte map stores of the two-column kernel (ssim_kernels.hip, MAP == 2)
     for (uint32_t i = 0; i < count && geo.map_unit; ++i)
         geo.map_unit = descs[i].map != NULL && descs[i].map_step == 1;

@@ -899,7 +899,12 @@ struct Slot1 {
     float x[ROW_PX];    // a*b
 };
 
-template <int MODE, bool MAP>
+// WIDE: 64-bit coordinates and per-lane 64-bit offsets (pairs fits_strip2() rejects).  !WIDE (round 3; every other launch):
+// the two-column kernel's addressing -- 32-bit coordinates on the scalar unit, a wave-uniform 64-bit row base plus a
+// loop-invariant non-negative 32-bit lane offset per load (global_load "saddr" form), the map through a branch-free raw
+// buffer store -- which removes ~10 VALU instructions per pixel of address arithmetic and 64-bit compares from the row
+// loop (MODE_DOUBLE: 147 -> 138 issue slots per pixel).
+template <int MODE, bool MAP, bool WIDE>
 __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
 {
     constexpr int PAD = Slot1::PAD, ROW_PX = Slot1::ROW_PX;
@@ -918,33 +923,42 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     const int lane = threadIdx.x;
     const Strip st = strip_setup(args, Slot1::STRIP_W);
     const PairDesc& pd = st.pd;
-    const int64_t W = st.W, H = st.H, x0 = st.x0, y0 = st.y0, y_end = st.y_end;
+    typedef typename std::conditional<WIDE, int64_t, int>::type idx_t;       // coordinates
+    typedef typename std::conditional<WIDE, int64_t, uint32_t>::type off_t;  // per-lane byte offsets
+    const idx_t W = (idx_t)st.W, H = (idx_t)st.H, x0 = (idx_t)st.x0, y0 = (idx_t)st.y0, y_end = (idx_t)st.y_end;
 
-    int     sp[NLOAD];
-    int64_t offA[NLOAD], offB[NLOAD];
+    // Staging columns: slot pixel p is image column clamp(x0 - PAD + p).  !WIDE: offsets are relative to the strip's
+    // lowest-addressed column so that they are non-negative and fit 32 bits (see ssim_strip2_kernel).
+    auto clampx = [&](idx_t x) { return x < 0 ? (idx_t)0 : (x > W - 1 ? W - 1 : x); };
+    const idx_t x_lo = clampx(x0 - PAD), x_hi = clampx(x0 - PAD + ROW_PX - 1);
+    const idx_t refA = WIDE ? (idx_t)0 : (pd.a_step >= 0 ? x_lo : x_hi), refB = WIDE ? (idx_t)0 : (pd.b_step >= 0 ? x_lo : x_hi);
+    const gptr_u8 baseA = (gptr_u8)pd.a + (int64_t)refA * pd.a_step;
+    const gptr_u8 baseB = (gptr_u8)pd.b + (int64_t)refB * pd.b_step;
+    int   sp[NLOAD];
+    off_t offA[NLOAD], offB[NLOAD];
 #pragma unroll
     for (int t = 0; t < NLOAD; ++t) {
         int p = lane + 64 * t;
         p = p < ROW_PX ? p : ROW_PX - 1;
-        int64_t xg = x0 - PAD + p;
-        xg = xg < 0 ? 0 : (xg > W - 1 ? W - 1 : xg);
+        const idx_t xg = clampx(x0 - PAD + p);
         sp[t] = p;
-        offA[t] = xg * pd.a_step;
-        offB[t] = xg * pd.b_step;
+        offA[t] = (off_t)((int64_t)(xg - refA) * pd.a_step);
+        offB[t] = (off_t)((int64_t)(xg - refB) * pd.b_step);
     }
 
     uint8_t va[NLOAD], vb[NLOAD];
-    auto fetch_to = [&](int64_t r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {
-        const int64_t ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
-        const gptr_u8 ra = (gptr_u8)pd.a + ry * pd.a_stride;
-        const gptr_u8 rb = (gptr_u8)pd.b + ry * pd.b_stride;
+    auto fetch_to = [&](idx_t r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {
+        const idx_t ry = r < 0 ? (idx_t)0 : (r > H - 1 ? H - 1 : r);
+        const gptr_u8 ra = baseA + (int64_t)ry * pd.a_stride;
+        const gptr_u8 rb = baseB + (int64_t)ry * pd.b_stride;
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
+            if constexpr (!WIDE) asm volatile("" : "+v"(offA[t]), "+v"(offB[t]));   // keeps the zero-extension foldable into the load (ssim_strip2_kernel)
             oa[t] = ra[offA[t]];
             ob[t] = rb[offB[t]];
         }
     };
-    auto fetch = [&](int64_t r) { fetch_to(r, va, vb); };
+    auto fetch = [&](idx_t r) { fetch_to(r, va, vb); };
     auto stage_from = [&](Slot1& s, const uint8_t (&ia)[NLOAD], const uint8_t (&ib)[NLOAD]) {
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
@@ -971,11 +985,15 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         accX[k] = VT<XV>::splat(0);
     }
     double colsum = 0.0;
-    const int64_t xcol = x0 + lane;
+    const idx_t xcol = x0 + lane;
     const bool col_ok = xcol < W;
-    const int64_t map_off = MAP ? xcol * pd.map_step : 0;
+    const int64_t map_off = (MAP && WIDE) ? (int64_t)xcol * pd.map_step : 0;
+    // !WIDE map addressing, like the loads: uniform row base + non-negative 32-bit byte offset; a lane beyond the image
+    // carries an out-of-range offset and the raw buffer store drops it (no exec masking in the row loop)
+    const idx_t refM = pd.map_step >= 0 ? x0 : (x0 + Slot1::STRIP_W - 1 < W ? x0 + Slot1::STRIP_W - 1 : W - 1);
+    const uint32_t offM = (MAP && !WIDE) ? (col_ok ? (uint32_t)((int64_t)(xcol - refM) * pd.map_step * 4) : 0x80000000u) : 0u;
 
-    const int64_t r_begin = y0 - 5;
+    const idx_t r_begin = y0 - 5;
     {   // three rows requested back to back, as in the two-column kernel
         uint8_t a0[NLOAD], b0[NLOAD], a1[NLOAD], b1[NLOAD];
         fetch_to(r_begin, a0, b0);
@@ -1012,7 +1030,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
             blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
     };
 
-    auto row = [&](const int64_t r, auto slot, auto phase_tag) {
+    auto row = [&](const idx_t r, auto slot, auto phase_tag) {
         constexpr int cur = decltype(slot)::value;
         constexpr int phase = decltype(phase_tag)::value;
         const Slot1& s = ring[cur];
@@ -1049,8 +1067,13 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
                 colsum += (double)v;
                 vmap = v;
             }
-            if constexpr (MAP) {
+            if constexpr (MAP && WIDE) {
                 if (col_ok) __builtin_nontemporal_store(vmap, &((gptr_f32)pd.map)[(r - 5) * pd.map_stride + map_off]);   // see SSIM_MAP_STORE_AUX
+            }
+            if constexpr (MAP && !WIDE) {
+                float* mrow = pd.map + ((int64_t)(r - 5) * pd.map_stride + (int64_t)refM * pd.map_step);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mrow, 0, 0x7FFFFFFF, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vmap), rs, offM, 0, SSIM_MAP_STORE_AUX);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -1066,7 +1089,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
-    int64_t r = r_begin;
+    idx_t r = r_begin;
 #pragma unroll 1
     for (int i = 0; i < 5; ++i, r += 2) {
         row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
@@ -1075,7 +1098,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     const int cell_rows = 1 << args.cell_shift;
     uint32_t cell_y = (uint32_t)(y0 >> args.cell_shift), parked = 0;
 #pragma unroll 1
-    for (int64_t left = y_end - y0; left > 0; left -= cell_rows) {
+    for (idx_t left = y_end - y0; left > 0; left -= cell_rows) {
         const int rows = left < cell_rows ? (int)left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
@@ -1146,8 +1169,13 @@ template <int MODE>
 hipError_t launch_strip1(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
-    if (map) hipLaunchKernelGGL((ssim_strip1_kernel<MODE, true>), grid, block, 0, stream, ka);
-    else     hipLaunchKernelGGL((ssim_strip1_kernel<MODE, false>), grid, block, 0, stream, ka);
+    if (geo.wide) {
+        if (map) hipLaunchKernelGGL((ssim_strip1_kernel<MODE, true, true>), grid, block, 0, stream, ka);
+        else     hipLaunchKernelGGL((ssim_strip1_kernel<MODE, false, true>), grid, block, 0, stream, ka);
+    } else {
+        if (map) hipLaunchKernelGGL((ssim_strip1_kernel<MODE, true, false>), grid, block, 0, stream, ka);
+        else     hipLaunchKernelGGL((ssim_strip1_kernel<MODE, false, false>), grid, block, 0, stream, ka);
+    }
     return hipGetLastError();
 }
 
@@ -1264,6 +1292,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     Geometry g;
     g.width = width; g.height = height; g.count = count;
     g.map_unit = false;
+    g.wide = true;          // safe default; the caller clears it when every pair passes fits_strip2()
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     g.cell_rows = cell_rows_for(height);
