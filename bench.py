@@ -55,11 +55,11 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH
 # VALU work per output pixel, lane-ops: exact = 5 planes x (5 fold adds + 6 mul + 30 fma + 10 ring adds) = 255
 # + 23 for the SSIM formula / divide / fp64 accumulate; fast (hybrid) = 3 reference-order planes x 51 + 2 separable planes
 # x 22 + 23; separable = 4 planes x 22 + 23 + 8 (a^2 + b^2 is blurred as one plane; centring and the restored mu);
-# fp64 mode: VALU ISSUE SLOTS per pixel counted in the compiled hot loop (tools/isa_mix.py: 279 VALU instructions per two
+# fp64 mode: VALU ISSUE SLOTS per pixel counted in the compiled hot loop (tools/isa_mix.py: 274 VALU instructions per two
 # rows of one pixel per lane) -- 88 fp64 multiply-adds of the blur and the formula, 25 fp32->fp64 conversions of the folded
-# sums, 10 packed fold adds, 17 of staging / in-range division / map value; every non-packed instruction
+# sums, 10 packed fold adds, 14 of staging / in-range division / map value; every non-packed instruction
 # occupies one fp64-rate slot, which is what the 39.3 T/s peak counts (round 2 counted the 88 blur operations only)
-VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 140, 3: 278, 4: 119}
+VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 137, 3: 278, 4: 119}
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)

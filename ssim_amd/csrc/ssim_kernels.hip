@@ -1008,18 +1008,26 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     const int base = lane + PAD - 5;
     f2 wab[11], wq[11];
     float wx[11];
+    // The lane's window addresses of both slots, kept in registers: the compiler pairs adjacent 8-byte reads into
+    // ds_read2_b64, whose offset field reaches 2040 bytes only -- without the pinned pointers it rebuilds "slot base +
+    // constant" with a VALU add for most reads of the second slot, every row (7 v_add_u32 per two rows).
+    typedef const f2 __attribute__((address_space(3)))* lptr_f2;
+    lptr_f2 pab0 = (lptr_f2)&ring[0].ab[base], pab1 = (lptr_f2)&ring[1].ab[base];
+    lptr_f2 pq0 = (lptr_f2)&ring[0].q[base], pq1 = (lptr_f2)&ring[1].q[base];
+    asm volatile("" : "+v"(pab0), "+v"(pab1), "+v"(pq0), "+v"(pq1));
     // folded (a,b) sums of the row about to be blurred + its centre pixel, carried over the loop edge
     f2 fa[5], ca;
-    auto load_ab = [&](const Slot1& s) {
+    auto load_ab = [&](int slot) {
+        const lptr_f2 p = slot ? pab1 : pab0;
 #pragma unroll
-        for (int t = 0; t < 11; ++t) wab[t] = s.ab[base + t];
+        for (int t = 0; t < 11; ++t) wab[t] = p[t];
     };
     auto fold_ab = [&]() {
         ca = wab[5];
 #pragma unroll
         for (int i = 1; i <= 5; ++i) fa[i - 1] = wab[5 + i] + wab[5 - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
     };
-    load_ab(ring[0]);
+    load_ab(0);
     fold_ab();
 
     auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream) {
@@ -1036,9 +1044,10 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         const Slot1& s = ring[cur];
         __builtin_amdgcn_s_setprio(2);               // see ssim_strip2_kernel
         __builtin_amdgcn_sched_barrier(0);
+        const lptr_f2 pq = cur ? pq1 : pq0;
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
-            wq[t] = s.q[base + t];
+            wq[t] = pq[t];
             if constexpr (!FOUR) wx[t] = s.x[base + t];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1046,7 +1055,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
         blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0], std::false_type());
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (phase != ROW_LAST) load_ab(ring[cur ^ 1]);
+        if constexpr (phase != ROW_LAST) load_ab(cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FOUR)
             blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type());
