@@ -205,15 +205,19 @@ __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V
 // multiply-adds form one dependent chain, and back-to-back dependent packed instructions cost a wait state each on
 // gfx950 (the compiler pads them with s_nop) -- with two waves per SIMD there is nobody else to fill those slots.
 template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
-__device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11], const V (&a)[6], const V (&b)[6], const G (&g)[6])
+__device__ __forceinline__ void separable_rows_pair(V& hA, V& hB, const V (&a)[6], const V (&b)[6], const G (&g)[6])
 {
-    V hA = a[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
-    V hB = b[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
+    hA = a[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
+    hB = b[tap_at<ORDER>(0)] * VT<V>::splat(g[tap_at<ORDER>(0)]);
 #pragma unroll
     for (int k = 1; k < 6; ++k) {
         hA = fma_(a[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), hA);
         hB = fma_(b[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), hB);
     }
+}
+template <typename V, typename G>
+__device__ __forceinline__ void separable_columns_pair(V (&accA)[11], V (&accB)[11], V hA, V hB, const G (&g)[6])
+{
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         const int t = k < 5 ? 5 - k : k - 5;
@@ -222,6 +226,13 @@ __device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11]
     }
     accA[10] = hA * VT<V>::splat(g[5]);
     accB[10] = hB * VT<V>::splat(g[5]);
+}
+template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
+__device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11], const V (&a)[6], const V (&b)[6], const G (&g)[6])
+{
+    V hA, hB;
+    separable_rows_pair<ORDER>(hA, hB, a, b, g);
+    separable_columns_pair(accA, accB, hA, hB, g);
 }
 
 // Per-pixel SSIM, unfused fp32 exactly as src/ssim.cpp:681-693 / src/ssim_avx.cpp:342-352.
@@ -692,6 +703,12 @@ void ssim_strip2_kernel(const KArgs args)
     // Folded (a,b) sums of the row about to be blurred, and its two centre pixels: computed at the END of the
     // previous iteration (where the window reads they consume are long complete) and carried over the loop edge.
     f2 fa[2][5], ca[2];
+    f2 hab[2];      // separable (a,b) streams (MODE_FAST, MODE_SEPARABLE): the finished ROW pass is what crosses the loop edge (4
+                    // registers instead of 24) and its dependent chain of six multiply-adds runs with the fold, in the
+                    // low-priority phase of the row: hybrid +2.5...5 % (32 x 4096^2 237.5 -> 243.8 Gpix/s, 32 x 1080p 222 -> 234;
+                    // 256 x 1080p -1.3 %), separable +0...1 % and 168 -> 152 VGPRs (profiles/r03_rowpass_ab.txt).  The same
+                    // move for MODE_EXACT's (a,b) row sums was measured too: +1...4 % on launches of up to ~4 rounds of wave
+                    // slots, -2...-6 % on longer ones (256 x 1080p 203 -> 190): not adopted.
     auto fold_ab = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -701,6 +718,11 @@ void ssim_strip2_kernel(const KArgs args)
             for (int i = 1; i <= 5; ++i) fa[c][i - 1] = wab[m + i] + wab[m - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
         }
         asm volatile("" :: "v"(wab[0]), "v"(wab[13]));   // see load_ab
+        if constexpr (HYB || FAST) {
+            const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
+            const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
+            separable_rows_pair<ORDER_CENTRE_FIRST>(hab[0], hab[1], s0, s1, gf);
+        }
     };
     load_ab(ring[0]);
     fold_ab();
@@ -750,9 +772,7 @@ void ssim_strip2_kernel(const KArgs args)
 #pragma unroll
             for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
         } else {
-            const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
-            const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
-            blur_separable_pair<ORDER_CENTRE_FIRST>(accAB[0], accAB[1], s0, s1, gf);
+            separable_columns_pair(accAB[0], accAB[1], hab[0], hab[1], gf);      // the row pass ran with the fold (fold_ab)
         }
         // (4) the (a*a,b*b) streams / MODE_SEPARABLE: the (a'*a' + b'*b', a'b') streams
         __builtin_amdgcn_sched_barrier(0);
