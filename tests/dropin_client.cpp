@@ -47,15 +47,14 @@ int main(int argc, char** argv)
     for (int c = 0; c < channels; ++c) {
         params.imgA.init_interleaved(&a[0], width * channels, channels, c);
         params.imgB.init_interleaved(&b[0], width * channels, channels, c);
-#if defined(__GNUC__)
-    #pragma GCC diagnostic push
-    #pragma GCC diagnostic ignored "-Wdeprecated-declarations"
-#endif
+        // the header's own diagnostics macros, used the way the reference's tests use them (tests/rmgr-ssim-tests.cpp:35-40)
+        RMGR_WARNING_PUSH()
+        RMGR_WARNING_MSVC_DISABLE(4996)
+        RMGR_WARNING_GCC_DISABLE("-Wdeprecated-declarations")
+        RMGR_WARNING_CLANG_DISABLE("-Wdeprecated-declarations")
         const float ssim = rmgr::ssim::compute_ssim(params);
         const int   err  = rmgr::ssim::get_errno(ssim);
-#if defined(__GNUC__)
-    #pragma GCC diagnostic pop
-#endif
+        RMGR_WARNING_POP()
         if (err != 0) {
             printf("channel %d errno %d\n", c, err);
             continue;

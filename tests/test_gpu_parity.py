@@ -290,6 +290,19 @@ def test_reference_style_cxx98_client_on_gpu(tmp_path, manifest, static):
         fields = out[1 + c].split()
         assert fields[:4] == ["channel", str(c), "ssim", want], out[1 + c]
         assert fields[4:8] == ["openmp_rc", "0", "openmp", want], out[1 + c]
+    # the same program on a full-size frame of the reference's bbb1080 set (interleaved RGB, 1920 x 1080, JPEG quality 50)
+    from conftest import _decode_rgb
+    import json
+    ref = json.load(open(os.path.join(GOLDEN, "refsets.json")))["sets"]["bbb1080"]["pairs"]
+    e = ref["q50_ch0"]
+    pa, pb = str(tmp_path / "a.rgb.u8"), str(tmp_path / "b.rgb.u8")
+    np.ascontiguousarray(_decode_rgb(e["a_file"])).tofile(pa)
+    np.ascontiguousarray(_decode_rgb(e["b_file"])).tofile(pb)
+    out = subprocess.run([exe, pa, pb, str(e["width"]), str(e["height"]), "3"], check=True, capture_output=True, text=True).stdout.splitlines()
+    for c in range(3):
+        want = ref["q50_ch%d" % c]["fma"]["ssim_hex"]
+        fields = out[1 + c].split()
+        assert fields[:4] == ["channel", str(c), "ssim", want] and fields[4:8] == ["openmp_rc", "0", "openmp", want], out[1 + c]
 
 
 def test_batch_equals_single_calls(gpu_ctx, oracle):
