@@ -17,7 +17,7 @@ HIPFLAGS := $(if $(DOUBLE),-DRMGR_SSIM_USE_DOUBLE=1) --offload-arch=$(ARCH) -O3 
 
 all: lib oracle
 
-lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(BIN)/rmgr-ssim
+lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim-hip-double.so $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(BIN)/rmgr-ssim
 
 # Static flavour under the reference's archive name (CMakeLists.txt:205): the same three objects.  A program
 # that links it also needs the HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
@@ -53,6 +53,18 @@ $(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/s
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
+# The reference's RMGR_SSIM_USE_DOUBLE build configuration (CMakeLists.txt:53, src/ssim_internal.h:26-37) as a second
+# flavour of the same library: identical kernels and drop-in layer, only the C ABI's default arithmetic differs (fp64
+# internals for every unchanged rmgr_ssim_compute_ssim call; BASELINE.json configs[4]).  `make DOUBLE=1` gives the same
+# thing under the main name.
+$(OBJ)/ssim_hip_abi_double.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h include/rmgr/ssim-hip.h include/rmgr/ssim.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -DRMGR_SSIM_USE_DOUBLE=1 -x hip -c $< -o $@
+
+$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o
+	@mkdir -p $(OUT)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
 # The command-line tool: plain host C++ on top of the C ABI (reference: src/ssim-cli.cpp).
 $(BIN)/rmgr-ssim: $(SRC)/ssim_cli.cpp $(OUT)/librmgr-ssim-hip.so include/rmgr/ssim.h include/rmgr/ssim-hip.h
 	@mkdir -p $(BIN)
@@ -67,7 +79,7 @@ PREFIX ?= /usr/local
 install: lib
 	install -d $(DESTDIR)$(PREFIX)/include/rmgr $(DESTDIR)$(PREFIX)/lib $(DESTDIR)$(PREFIX)/bin $(DESTDIR)$(PREFIX)/lib/pkgconfig
 	install -m 644 include/rmgr/ssim.h include/rmgr/ssim-openmp.h include/rmgr/ssim-version.h include/rmgr/ssim-hip.h $(DESTDIR)$(PREFIX)/include/rmgr/
-	install -m 755 $(OUT)/librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/
+	install -m 755 $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim-hip-double.so $(DESTDIR)$(PREFIX)/lib/
 	install -m 644 $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(DESTDIR)$(PREFIX)/lib/
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim.so
 	ln -sf librmgr-ssim-hip.so $(DESTDIR)$(PREFIX)/lib/librmgr-ssim-openmp.so

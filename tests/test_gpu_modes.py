@@ -179,3 +179,31 @@ def test_process_wide_mode_switch(manifest):
     assert np.float32(out["3"]) == np.float32(float(ent["avx"]["ssim"]))
     assert abs(out["2"] - float(ent["naive_f64"]["ssim"])) <= 6e-8 + 1e-9
     assert out["2"] != out["0"]
+
+
+def test_double_build_flavour_of_the_library(manifest):
+    """The reference's RMGR_SSIM_USE_DOUBLE is a BUILD option (CMakeLists.txt:53): `make lib` therefore also produces
+    librmgr-ssim-hip-double.so, the same library compiled with -DRMGR_SSIM_USE_DOUBLE=1.  Without any environment variable or
+    mode call the unchanged drop-in entry point must compute with fp64 internals there (naive<double>'s value, map within 1e-7),
+    report mode 2, and stay double when select_impl-style code asks for the FMA / generic arithmetic."""
+    import subprocess
+    import sys
+    ent = manifest["einstein_jpg"]
+    lib = os.path.join(os.path.dirname(ssim_amd.LIB_PATH), "librmgr-ssim-hip-double.so")
+    assert os.path.exists(lib), "make lib builds the double flavour"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, ctypes, numpy as np; sys.path.insert(0, %r); import ssim_amd; "
+            "a=np.fromfile(%r,np.uint8).reshape(256,256); b=np.fromfile(%r,np.uint8).reshape(256,256); "
+            "v,m=ssim_amd.compute_ssim(a,b,want_map=True); nm=np.load(%r); "
+            "mode=ctypes.c_int32(-1); ssim_amd.load_library().rmgr_ssim_hip_get_mode(None, ctypes.byref(mode)); "
+            "ssim_amd.load_library().rmgr_ssim_hip_set_mode(None, 0); v2,_=ssim_amd.compute_ssim(a,b); "
+            "print(repr(float(v)), mode.value, repr(float(np.abs(m.astype(np.float64)-nm).max())), repr(float(v2)))"
+            % (root, os.path.join(GOLDEN, ent["a"]), os.path.join(GOLDEN, ent["b"]), os.path.join(GOLDEN, ent["naive_f64"]["map"])))
+    env = dict(os.environ, RMGR_SSIM_LIB=lib)
+    env.pop("RMGR_SSIM_HIP_MODE", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    v, mode, worst, v2 = r.stdout.split()[-4:]
+    assert abs(float(v) - float(ent["naive_f64"]["ssim"])) <= 6e-8 + 1e-9 and int(mode) == 2 and float(worst) <= 1e-7
+    assert float(v2) == float(v)                                  # "a double build stays double"
+    assert np.float32(float(v)) != np.float32(float(ent["fma"]["ssim"]))
