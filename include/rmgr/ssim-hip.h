@@ -58,8 +58,8 @@ rmgr_int32_t rmgr_ssim_hip_get_device_count(rmgr_int32_t* count) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** ctx, rmgr_int32_t device, void* stream) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 
-/* ctx == NULL: the process-wide default context the unchanged rmgr_ssim_compute_ssim() runs on (created on first use;
- * ENODEV without a device).  This is what rmgr::ssim::select_impl() calls (src/ssim.cpp:808-896). */
+/* ctx == NULL (set and get): the process-wide default context the unchanged rmgr_ssim_compute_ssim() runs on (created on
+ * first use; ENODEV without a device).  This is what rmgr::ssim::select_impl() calls (src/ssim.cpp:808-896). */
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mode) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
 

@@ -627,7 +627,16 @@ rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode)
 
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* c, rmgr_int32_t* mode) RMGR_NOEXCEPT
 {
-    if (!c || !mode) return EINVAL;
+    if (!mode) return EINVAL;
+    if (!c) {                 // the process-wide default context, as for set_mode (created on first use; ENODEV without a device)
+        int rc = 0;
+        rmgr_ssim_hip_Context* d = default_context(&rc);
+        if (rc) return rc;
+        if (!d) return ENODEV;
+        std::lock_guard<std::mutex> guard(d->lock);
+        *mode = d->mode;
+        return 0;
+    }
     *mode = c->mode;
     return 0;
 }
