@@ -64,7 +64,8 @@ rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mod
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
 
 /* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the kernel variant
- * (1: one column per lane, 2: two columns per lane; the default picks by launch size).  Results do not depend on
+ * (1: one column per lane, 2: two columns per lane, 3: two columns per lane with the bit-exact modes' (a,b) row sums formed a
+ * phase early; the default picks by launch size).  Results do not depend on
  * either (tests/test_gpu_parity.py, tests/test_gpu_pipeline.py check). */
 rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT;
 

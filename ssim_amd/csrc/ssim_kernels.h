@@ -32,6 +32,7 @@ struct Geometry {
     uint32_t cells_x, cells_y;    // the image's 64-column x cell_rows-row reduction cells (ssim_kernels.hip, cell_flush*)
     bool     map_unit;            // every pair of the launch writes its map with ssimStep == 1 (set by the caller of plan(); scheduling only)
     bool     wide;                // some pair needs the fully 64-bit form of the one-column kernel (!fits_strip2(); set by the caller of plan())
+    uint32_t wave_slots;          // strips the chip holds at a time with this kernel (SIMDs x waves per SIMD): plan()'s packing unit
     uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 

@@ -571,7 +571,11 @@ enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 // MAP: 0 no map; 1 map with any ssimStep (one 4-byte store per column); 2 every pair of the launch has ssimStep == 1
 // and the width is even (no lane owns a lone last column): the lane's two adjacent values go out as one 8-byte store
 // (a wave writes 512 contiguous bytes per row; +2...3 % for MODE_SEPARABLE with a map, neutral for MODE_EXACT).
-template <int MODE, int MAP>
+// EARLY (bit-exact modes only; round 3): the six row sums of the two (a,b) streams -- 72 packed instructions -- are formed with
+// the fold at the bottom of the previous iteration, in the wave's low-priority phase, and cross the loop edge instead of
+// the folded sums (24 registers either way); the high-priority phase then only scatters them into the ring.  Same
+// operations, same bits.  It pays on launches of few rounds of wave slots and costs on long ones (see launch()).
+template <int MODE, int MAP, bool EARLY = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_SEPARABLE ? 3 : 2, MODE == MODE_SEPARABLE ? 3 : 2)))
 void ssim_strip2_kernel(const KArgs args)
 {
@@ -703,6 +707,7 @@ void ssim_strip2_kernel(const KArgs args)
     // Folded (a,b) sums of the row about to be blurred, and its two centre pixels: computed at the END of the
     // previous iteration (where the window reads they consume are long complete) and carried over the loop edge.
     f2 fa[2][5], ca[2];
+    f2 sab[2][6];   // EARLY: the (a,b) streams' row sums S0..S5 of the row about to be scattered
     f2 hab[2];      // separable (a,b) streams (MODE_FAST, MODE_SEPARABLE): the finished ROW pass is what crosses the loop edge (4
                     // registers instead of 24) and its dependent chain of six multiply-adds runs with the fold, in the
                     // low-priority phase of the row: hybrid +2.5...5 % (32 x 4096^2 237.5 -> 243.8 Gpix/s, 32 x 1080p 222 -> 234;
@@ -722,6 +727,17 @@ void ssim_strip2_kernel(const KArgs args)
             const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
             const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
             separable_rows_pair<ORDER_CENTRE_FIRST>(hab[0], hab[1], s0, s1, gf);
+        }
+        if constexpr (EARLY && !FAST && !HYB) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                sab[c][0] = row_sum<0, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+                sab[c][1] = row_sum<1, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+                sab[c][2] = row_sum<2, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+                sab[c][3] = row_sum<3, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+                sab[c][4] = row_sum<4, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+                sab[c][5] = row_sum<5, FUSED>(ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+            }
         }
     };
     load_ab(ring[0]);
@@ -768,7 +784,15 @@ void ssim_strip2_kernel(const KArgs args)
         }
         // (3) row sums + ring scatter of the (a,b) streams while those reads are in flight
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!FAST && !HYB) {
+        if constexpr (!FAST && !HYB && EARLY) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {       // the ring scatter of blur_exact, on row sums formed at fold time
+                f2 (&acc)[11] = accAB[c];
+                acc[0] = sab[c][5] + acc[1]; acc[1] = sab[c][4] + acc[2]; acc[2] = sab[c][3] + acc[3]; acc[3] = sab[c][2] + acc[4];
+                acc[4] = sab[c][1] + acc[5]; acc[5] = sab[c][0] + acc[6]; acc[6] = sab[c][1] + acc[7]; acc[7] = sab[c][2] + acc[8];
+                acc[8] = sab[c][3] + acc[9]; acc[9] = sab[c][4] + acc[10]; acc[10] = sab[c][5];
+            }
+        } else if constexpr (!FAST && !HYB) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
         } else {
@@ -1185,9 +1209,17 @@ __global__ __launch_bounds__(kReduceThreads) void ssim_reduce_kernel(const doubl
 }
 
 template <int MODE>
-hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream)
+hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream, bool early)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
+    if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
+        if (early) {
+            if (!map)              hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, true>), grid, block, 0, stream, ka);
+            else if (geo.map_unit) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 2, true>), grid, block, 0, stream, ka);
+            else                   hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 1, true>), grid, block, 0, stream, ka);
+            return hipGetLastError();
+        }
+    }
     if (!map)              hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0>), grid, block, 0, stream, ka);
     else if (geo.map_unit) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 2>), grid, block, 0, stream, ka);
     else                   hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 1>), grid, block, 0, stream, ka);
@@ -1322,6 +1354,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.width = width; g.height = height; g.count = count;
     g.map_unit = false;
     g.wide = true;          // safe default; the caller clears it when every pair passes fits_strip2()
+    g.wave_slots = (uint32_t)((cu_count > 0 ? cu_count : 256) * 4 * waves_per_simd(mode, variant));
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
     g.cell_rows = cell_rows_for(height);
@@ -1393,6 +1426,19 @@ hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hi
     return hipGetLastError();
 }
 
+// Which launches run the EARLY form of the bit-exact two-column kernel by default.  Measured with both forms interleaved in
+// one process over batch sizes (profiles/r03_early_sweep.txt; rounds = strips / wave slots of the chip): up to ~2 rounds EARLY
+// wins 2.4...5 % (one 4096^2 pair 169.5 -> 173.5 Gpix/s, 8 x 4096^2 201 -> 206, 2 x 8192^2 + map 190 -> 200, 32 x 1080p
+// 186 -> 193), around 3 rounds +1 %, at 4 rounds +-0.4 %, and on longer launches it LOSES (192 / 256 / 384 x 1080p -3 / -4 /
+// -2.5 %; 64...128 x 4096^2 -0...0.5 %).  Why the sign flips with the launch length is not understood (more VALU work in the
+// low-priority phase; the waves of long launches start staggered, those of one-round launches in lockstep), so the rule is
+// the measured one.
+static bool early_row_sums_pay(const Geometry& geo)
+{
+    const uint64_t strips = (uint64_t)geo.strips_x * geo.strips_y * geo.count;
+    return geo.wave_slots != 0 && strips <= 3ull * geo.wave_slots;
+}
+
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce)
 {
@@ -1430,14 +1476,15 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
         return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
     hipError_t err;
-    // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel).
-    // MODE_DOUBLE always runs one column per lane.
+    // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel); tuning: 2 forces the
+    // two-column kernel with its row sums in the blur phase, 3 with EARLY row sums.  MODE_DOUBLE always runs one column per lane.
     const bool one = columns_per_lane(mode, variant) == 1;
+    const bool early = variant == 3 || (variant == 0 && early_row_sums_pay(geo));
     switch (mode) {
-    case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream);   break;
-    case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream); break;
-    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream);    break;
-    case MODE_SEPARABLE: err = one ? launch_strip1<MODE_SEPARABLE>(geo, ka, map, stream) : launch_strip2<MODE_SEPARABLE>(geo, ka, map, stream); break;
+    case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream, early);   break;
+    case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream, early); break;
+    case MODE_FAST:    err = one ? launch_strip1<MODE_FAST>(geo, ka, map, stream)    : launch_strip2<MODE_FAST>(geo, ka, map, stream, false);    break;
+    case MODE_SEPARABLE: err = one ? launch_strip1<MODE_SEPARABLE>(geo, ka, map, stream) : launch_strip2<MODE_SEPARABLE>(geo, ka, map, stream, false); break;
     case MODE_DOUBLE:  err = launch_strip1<MODE_DOUBLE>(geo, ka, map, stream); break;
     default:           return hipErrorInvalidValue;
     }

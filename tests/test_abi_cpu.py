@@ -286,8 +286,9 @@ def test_kernels_keep_two_waves_per_simd_and_never_spill():
             if m and name:
                 kernels[name][key.split(" ")[0]] = int(m.group(1))
     strip = {k: v for k, v in kernels.items() if "ssim_strip" in k}
-    # two-column kernel: 4 fp32 modes x {no map, map, map with 8-byte stores}; one-column kernel: 5 modes x {no map, map} x {64-bit, 32-bit addressing}
-    assert len(strip) == 32, sorted(kernels)
+    # two-column kernel: 4 fp32 modes x {no map, map, map with 8-byte stores} + the EARLY form of the two bit-exact modes;
+    # one-column kernel: 5 modes x {no map, map} x {64-bit, 32-bit addressing}
+    assert len(strip) == 38, sorted(kernels)
     for k, v in strip.items():
         assert v["ScratchSize"] == 0, (k, v)
         assert v["VGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)

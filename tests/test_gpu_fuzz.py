@@ -50,7 +50,7 @@ def test_random_layouts_bit_exact(gpu_ctx, oracle):
         a = rng.integers(0, 256, (h, w), dtype=np.uint8)
         b = np.clip(a.astype(np.int32) + rng.integers(-30, 31, (h, w)), 0, 255).astype(np.uint8) if rng.integers(0, 3) else rng.integers(0, 256, (h, w), dtype=np.uint8)
         fused = bool(rng.integers(0, 4))                      # mostly the FMA order, sometimes the unfused one
-        variant, rows = int(rng.integers(0, 3)), int(rng.choice([0, 0, 1, 3, 16, 50]))   # 0 default, 1 one column, 2 two columns
+        variant, rows = int(rng.integers(0, 4)), int(rng.choice([0, 0, 1, 3, 16, 50]))   # 0 default, 1 one column, 2 two columns, 3 two columns with early row sums
         ov, osum, om = oracle.ssim_f32(a, b, want_map=True, fused=fused)
 
         ba, oa, sa, da_ = make_layout(rng, a)

@@ -425,7 +425,7 @@ def test_full_size_known_answers_and_properties(gpu_ctx, oracle, manifest):
         pm = ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, db.ptr, 1, 4096, dm.ptr, 1, 4096)
         gpu_ctx.compute_device(pm)
         base = dm.download(np.float32, (4096, 4096))
-        for rows, variant in ((32, 0), (100, 0), (77, 0), (0, 1)):
+        for rows, variant in ((32, 0), (100, 0), (77, 0), (0, 1), (0, 2), (0, 3)):
             gpu_ctx.set_tuning(rows, variant)
             assert f32_hex(gpu_ctx.compute_device(pm)) == f32_hex(v)
             assert_same_map(dm.download(np.float32, (4096, 4096)), base, (rows, variant))

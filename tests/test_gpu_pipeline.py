@@ -102,7 +102,7 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
         ref = batch_sums(gpu_ctx, pairs, keep)
         assert np.all(np.isfinite(ref))
         for strip_rows, variant, split in ((8, 2, None), (24, 0, None), (64, 1, None), (216, 2, None), (512, 1, None),
-                                           (0, 1, None), (0, 2, None), (0, 0, [(0, 1), (1, 4), (4, 6)]), (40, 0, [(0, 5), (5, 6)])):
+                                           (0, 1, None), (0, 2, None), (0, 3, None), (48, 3, None), (0, 0, [(0, 1), (1, 4), (4, 6)]), (40, 0, [(0, 5), (5, 6)])):
             gpu_ctx.set_tuning(strip_rows, variant)
             got = batch_sums(gpu_ctx, pairs, keep, split)
             assert np.array_equal(bits64(got), bits64(ref)), (mode, strip_rows, variant, split, got - ref)

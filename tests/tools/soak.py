@@ -21,7 +21,7 @@ for case in range(CASES):
     b=np.clip(a.astype(np.int32)+rng.integers(-40,41,(h,w)),0,255).astype(np.uint8)
     mode=int(rng.choice([0,0,0,3,1,1,4,4,2]))
     ba,oa,sa,da_=make_layout(rng,a); bb,ob,sb,db_=make_layout(rng,b)
-    variant=int(rng.integers(0,3)); rows=int(rng.choice([0,0,2,9,31,64,300]))
+    variant=int(rng.integers(0,4)); rows=int(rng.choice([0,0,2,9,31,64,300]))
     keep=[]
     try:
         da,db=ctx.upload(ba),ctx.upload(bb); dm=ctx.alloc(4*w*h); keep+=[da,db,dm]
