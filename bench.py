@@ -210,12 +210,13 @@ def attainable_hbm_gbs(torch, dev):
     return round(2.0 * n / (best * 1e-3) / 1e9, 1)
 
 
-def kernel_name(mode, variant, want_map):
+def kernel_name(mode, variant, want_map, early=False):
     """Template instance rocprofv3 lists for this configuration (ssim_kernels.hip): the two-column kernel's second argument
-    is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even); the one-column kernel's is a bool."""
+    is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even), its third whether the bit-exact modes run their
+    EARLY form (short launches; rmgr_ssim_hip_get_plan tells); the one-column kernel's are bools (map, 64-bit addressing)."""
     if mode == 2 or variant == 1:
         return "ssim_strip1_kernel<%d, %s, false>" % (mode, "true" if want_map else "false")     # last argument: 64-bit addressing (never needed by the bench's pairs)
-    return "ssim_strip2_kernel<%d, %d>" % (mode, 2 if want_map else 0)
+    return "ssim_strip2_kernel<%d, %d, %s>" % (mode, 2 if want_map else 0, "true" if early else "false")
 
 
 def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
@@ -256,6 +257,7 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
     batch = Batch(torch, ssim_amd, synth, ctx, dev, w, h, 0, pairs, want_map)
     sums = torch.zeros(pairs, dtype=torch.float64, device=dev)
     ctx.set_mode(mode)
+    early = bool(ssim_amd.get_plan(w, h, pairs, ctx).earlyRowSums)
     try:
         ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
         ctx.synchronize()
@@ -305,7 +307,7 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
     k_ms = ms / max(n, 1)
     roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
     return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
-            "kernel": kernel_name(mode, 0, want_map), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
+            "kernel": kernel_name(mode, 0, want_map, early), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
             "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
             "mpix_s_wall": round(float(pairs) * w * h * steps / wall / 1e6, 1),
             "roofline": roof, "valu": valu}
@@ -396,6 +398,7 @@ def main():
     first, last = table["shards"][rank]
     mine = last - first
     batch = Batch(torch, ssim_amd, synth, ctx, dev, W, H, first, mine, want_map)
+    headline_early = bool(mine and ssim_amd.get_plan(W, H, mine, ctx).earlyRowSums)
     sums_all = torch.zeros(total, dtype=torch.float64, device=dev)       # zero except this rank's slice
     work = torch.zeros_like(sums_all)
     my_slice_ptr = sums_all.data_ptr() + 8 * first
@@ -568,7 +571,7 @@ def main():
             roof.update({"traffic": measured_traffic(args.mode, args.workload, mine),
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes committed under profiles/ (traffic.json), scaled to this batch; null if unmeasured",
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
-                         "kernel": kernel_name(args.mode, args.variant, want_map), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
+                         "kernel": kernel_name(args.mode, args.variant, want_map, headline_early), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
             valu.update({"measured_peak": VALU_MEASURED_PEAK_TOPS, "frac_of_measured_peak": round(valu["achieved"] / VALU_MEASURED_PEAK_TOPS, 4),
                          "measured_peak_at_kernel_occupancy": VALU_MEASURED_2WAVE_TOPS,

@@ -78,6 +78,8 @@ typedef struct rmgr_ssim_hip_Plan
     rmgr_uint32_t stripRows;         /* output rows per wavefront */
     rmgr_uint32_t stripsX, stripsY;  /* strips per image */
     rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count = workgroups of the launch */
+    rmgr_uint32_t waveSlots;         /* wavefronts the device holds at a time with this kernel (SIMDs x waves per SIMD) */
+    rmgr_uint32_t earlyRowSums;      /* 1: the bit-exact two-column kernel runs in its EARLY form (launches of <= 3 x waveSlots wavefronts) */
 } rmgr_ssim_hip_Plan;
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT;
 

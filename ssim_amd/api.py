@@ -45,7 +45,7 @@ class Params(ctypes.Structure):
 
 class Plan(ctypes.Structure):
     _fields_ = [("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
-                ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32)]
+                ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32), ("waveSlots", ctypes.c_uint32), ("earlyRowSums", ctypes.c_uint32)]
 
 
 class ThreadPool(ctypes.Structure):

@@ -661,6 +661,8 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_
     plan->stripsX = geo.strips_x;
     plan->stripsY = geo.strips_y;
     plan->wavefronts = geo.strips_x * geo.strips_y * count;
+    plan->waveSlots = geo.wave_slots;
+    plan->earlyRowSums = ssim_hip::uses_early_row_sums(geo, mode, variant) ? 1u : 0u;
     return 0;
 }
 

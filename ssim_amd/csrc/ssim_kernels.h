@@ -86,6 +86,22 @@ inline int default_variant(uint32_t width, uint32_t height, uint32_t count, int 
 // cells -1.5...-3 %; profiles/r02_cells_ab.txt).
 inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8u; }
 
+// Which launches run the EARLY form of the bit-exact two-column kernel by default.  Measured with both forms interleaved in
+// one process over batch sizes (profiles/r03_early_sweep.txt; rounds = strips / wave slots of the chip): up to ~2 rounds EARLY
+// wins 2.4...5 % (one 4096^2 pair 169.5 -> 173.5 Gpix/s, 8 x 4096^2 201 -> 206, 2 x 8192^2 + map 190 -> 200, 32 x 1080p
+// 186 -> 193), around 3 rounds +1 %, at 4 rounds +-0.4 %, and on longer launches it LOSES (192 / 256 / 384 x 1080p -3 / -4 /
+// -2.5 %; 64...128 x 4096^2 -0...0.5 %).  Why the sign flips with the launch length is not understood (more VALU work in the
+// low-priority phase; the waves of long launches start staggered, those of one-round launches in lockstep), so the rule is
+// the measured one.
+inline bool uses_early_row_sums(const Geometry& geo, int mode, int variant)
+{
+    if ((mode != MODE_EXACT && mode != MODE_UNFUSED) || variant == 1 || geo.strip_w != 128) return false;
+    if (variant == 3) return true;
+    if (variant != 0) return false;
+    const uint64_t strips = (uint64_t)geo.strips_x * geo.strips_y * geo.count;
+    return geo.wave_slots != 0 && strips <= 3ull * geo.wave_slots;
+}
+
 // y_begin / y_rows: the output rows the launch produces (default: the whole image).  A host that pipelines an image
 // in row bands launches consecutive windows -- each starting on a cell boundary -- into the same partials and
 // asks for the reduction with the last one; the sums are bit-identical to the single launch's.

@@ -1426,19 +1426,6 @@ hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hi
     return hipGetLastError();
 }
 
-// Which launches run the EARLY form of the bit-exact two-column kernel by default.  Measured with both forms interleaved in
-// one process over batch sizes (profiles/r03_early_sweep.txt; rounds = strips / wave slots of the chip): up to ~2 rounds EARLY
-// wins 2.4...5 % (one 4096^2 pair 169.5 -> 173.5 Gpix/s, 8 x 4096^2 201 -> 206, 2 x 8192^2 + map 190 -> 200, 32 x 1080p
-// 186 -> 193), around 3 rounds +1 %, at 4 rounds +-0.4 %, and on longer launches it LOSES (192 / 256 / 384 x 1080p -3 / -4 /
-// -2.5 %; 64...128 x 4096^2 -0...0.5 %).  Why the sign flips with the launch length is not understood (more VALU work in the
-// low-priority phase; the waves of long launches start staggered, those of one-round launches in lockstep), so the rule is
-// the measured one.
-static bool early_row_sums_pay(const Geometry& geo)
-{
-    const uint64_t strips = (uint64_t)geo.strips_x * geo.strips_y * geo.count;
-    return geo.wave_slots != 0 && strips <= 3ull * geo.wave_slots;
-}
-
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce)
 {
@@ -1479,7 +1466,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel); tuning: 2 forces the
     // two-column kernel with its row sums in the blur phase, 3 with EARLY row sums.  MODE_DOUBLE always runs one column per lane.
     const bool one = columns_per_lane(mode, variant) == 1;
-    const bool early = variant == 3 || (variant == 0 && early_row_sums_pay(geo));
+    const bool early = uses_early_row_sums(geo, mode, variant);
     switch (mode) {
     case MODE_EXACT:   err = one ? launch_strip1<MODE_EXACT>(geo, ka, map, stream)   : launch_strip2<MODE_EXACT>(geo, ka, map, stream, early);   break;
     case MODE_UNFUSED: err = one ? launch_strip1<MODE_UNFUSED>(geo, ka, map, stream) : launch_strip2<MODE_UNFUSED>(geo, ka, map, stream, early); break;
