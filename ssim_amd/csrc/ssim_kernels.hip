@@ -711,9 +711,8 @@ void ssim_strip2_kernel(const KArgs args)
     f2 hab[2];      // separable (a,b) streams (MODE_FAST, MODE_SEPARABLE): the finished ROW pass is what crosses the loop edge (4
                     // registers instead of 24) and its dependent chain of six multiply-adds runs with the fold, in the
                     // low-priority phase of the row: hybrid +2.5...5 % (32 x 4096^2 237.5 -> 243.8 Gpix/s, 32 x 1080p 222 -> 234;
-                    // 256 x 1080p -1.3 %), separable +0...1 % and 168 -> 152 VGPRs (profiles/r03_rowpass_ab.txt).  The same
-                    // move for MODE_EXACT's (a,b) row sums was measured too: +1...4 % on launches of up to ~4 rounds of wave
-                    // slots, -2...-6 % on longer ones (256 x 1080p 203 -> 190): not adopted.
+                    // 256 x 1080p -1.3 %), separable +0...1 % and 168 -> 152 VGPRs (profiles/r03_rowpass_ab.txt).  The bit-exact
+                    // modes' counterpart is the EARLY form (template parameter): it only pays on short launches.
     auto fold_ab = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
