@@ -398,3 +398,28 @@ def test_reference_naive_header_compiles_against_this_header(tmp_path):
         r = subprocess.run(["g++", "-std=" + std, "-D_USE_MATH_DEFINES", "-fsyntax-only", "-Wall", "-I" + INCLUDE, "-I/root/reference/tests", str(tu)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("double", [False, True])
+def test_cmake_consumer_links_the_reference_target_names(tmp_path, double):
+    """Projects consume the reference with add_subdirectory() + target_link_libraries(app rmgr-ssim rmgr-ssim-openmp)
+    (reference CMakeLists.txt:205, :229).  The same two lines pointed at this repository must configure, build the C++98
+    client and link it against the HIP library (RMGR_SSIM_USE_DOUBLE, the reference's option, picks the fp64 flavour)."""
+    import shutil
+    if not shutil.which("cmake"):
+        pytest.skip("no cmake")
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "CMakeLists.txt").write_text(
+        "cmake_minimum_required(VERSION 3.16)\nproject(consumer CXX)\n"
+        "add_subdirectory(%s ssim)\nadd_executable(client %s)\n"
+        "set_target_properties(client PROPERTIES CXX_STANDARD 98 CXX_EXTENSIONS OFF)\n"
+        "target_link_libraries(client PRIVATE rmgr-ssim-openmp rmgr-ssim)\n" % (ROOT, os.path.join(ROOT, "tests", "dropin_client.cpp")))
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    r = subprocess.run(["cmake", "-S", str(src), "-B", str(tmp_path / "build")] + gen + (["-DRMGR_SSIM_USE_DOUBLE=ON"] if double else []),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(["cmake", "--build", str(tmp_path / "build")], capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = subprocess.run(["ldd", str(tmp_path / "build" / "client")], capture_output=True, text=True).stdout
+    assert ("librmgr-ssim-hip-double.so" if double else "librmgr-ssim-hip.so") in out, out
