@@ -37,7 +37,9 @@ extern "C" {
 #define RMGR_SSIM_HIP_MODE_FAST    1  /* the three E[.] planes in the reference's exact operation order (bit-identical planes), the two
                                          mu planes by a separable 11+11 fp32 blur: not bit-identical, but inside the reference's
                                          documented single-precision tolerance RELATIVE TO ITS FMA PATH (global 1.5e-6, per pixel
-                                         6.3e-4) on all five of the reference's test image sets, with >= 30 % / >= 60 % margin */
+                                         6.3e-4) on all five of the reference's test image sets, with >= 30 % / >= 60 % margin.  (On large flat
+                                         areas every pixel's rounding error has the same sign and the GLOBAL value can differ more --
+                                         DESIGN.md section 2; only modes 0 and 3 are guarantees) */
 #define RMGR_SSIM_HIP_MODE_DOUBLE  2  /* RMGR_SSIM_USE_DOUBLE semantics: fp64 internals, true double kernel (tests/ssim_naive.h) */
 #define RMGR_SSIM_HIP_MODE_UNFUSED 3  /* operation order of the reference's AVX/SSE/generic paths (mul and add rounded separately) */
 #define RMGR_SSIM_HIP_MODE_SEPARABLE 4 /* every plane by the separable 11+11 fp32 blur (four planes, centred pixels): the fastest mode and

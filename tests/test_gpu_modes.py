@@ -115,6 +115,43 @@ def test_fast_modes_reproduce_the_cpu_model_of_their_arithmetic(gpu_ctx, oracle,
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
 
 
+def test_fast_modes_on_flat_stress_images(gpu_ctx, oracle):
+    """Where the contracts of the non-bit-exact modes END (profiles/r03_adversarial.md): large flat areas with
+    +-1...2 of noise give every pixel's rounding error the same sign.  Per pixel both modes keep their bounds there -- MODE_FAST
+    <= 2.5e-4 from the FMA map (tolerance 6.3e-4), MODE_SEPARABLE <= 2.2e-4 from the exact map -- but a global value cannot
+    average same-sign deviations away: the reference itself is up to 6.5e-5 off the exact global value on these images (its
+    documented figure: 1.5e-6), MODE_FAST up to 3.8e-5 off the reference's.  Only the bit-exact modes carry a guarantee; this
+    test pins the measured regime so that the documentation stays true."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import fast_mode_model as model
+    threads = oracle.oracle_lib().oracle_max_threads()
+    worst = {"ref_glob": 0.0, "fast_px": 0.0, "fast_glob": 0.0, "sep_px": 0.0, "sep_glob_bright": 0.0}
+    try:
+        for name, a, b in model.adversarial_pairs():
+            fv, _, fm = oracle.ssim_f32(a, b, want_map=True, threads=threads)
+            nv, _, nm = oracle.ssim_naive_f64(a, b, want_map=True, threads=threads)
+            gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            assert np.array_equal(m.view(np.uint32), fm.view(np.uint32)) and np.float32(v) == np.float32(fv), name   # the guarantee
+            worst["ref_glob"] = max(worst["ref_glob"], abs(float(fv) - nv))
+            gpu_ctx.set_mode(ssim_amd.MODE_FAST)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            worst["fast_px"] = max(worst["fast_px"], float(np.abs(m.astype(np.float64) - fm.astype(np.float64)).max()))
+            worst["fast_glob"] = max(worst["fast_glob"], abs(float(v) - float(fv)))
+            gpu_ctx.set_mode(ssim_amd.MODE_SEPARABLE)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            worst["sep_px"] = max(worst["sep_px"], float(np.abs(m.astype(np.float64) - nm).max()))
+            if "flat 30" not in name:
+                worst["sep_glob_bright"] = max(worst["sep_glob_bright"], abs(float(v) - nv) / max(abs(float(fv) - nv), 1e-7))
+    finally:
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+    print("stress images:", worst)
+    assert worst["fast_px"] <= 2.5e-4 and worst["sep_px"] <= 2.2e-4                 # the per-pixel bounds hold
+    assert worst["ref_glob"] > 5e-5                                                 # the reference's own global error here ...
+    assert 1.5e-6 < worst["fast_glob"] <= 5e-5                                      # ... and MODE_FAST's global distance from it
+
+
 def test_double_mode_vs_naive_oracle(gpu_ctx, manifest, oracle):
     gpu_ctx.set_mode(ssim_amd.MODE_DOUBLE)
     try:

@@ -30,6 +30,7 @@ Reference values come from the oracle's C restatement (bit-identical to the real
 pairs: tests/test_oracle_golden.py), so the tool runs wherever the repository does; maps are cached under /tmp.
 
 usage: python tests/tools/fast_mode_model.py [form ...] [--sets einstein,bbb360,...] [--jobs 8]      (CPU only, ~3 min for all)
+       python tests/tools/fast_mode_model.py --adversarial      (synthetic flat / saturated stress images, profiles/r03_adversarial.md)
 """
 import hashlib
 import json
@@ -273,8 +274,50 @@ def work(task):
     return (form, set_name, name) + evaluate(FORMS[form][0], *load(set_name, name))
 
 
+def adversarial_pairs(H=384, W=512, seed=7):
+    """Synthetic stress images for the non-bit-exact modes: large flat (bright / mid / dark) areas with +-1...2 of noise,
+    where every pixel's rounding error has the same sign -- the regime in which a global value cannot average per-pixel
+    deviations away -- plus gradients, saturated patterns and uncorrelated / anti-correlated noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    u8 = lambda v: np.clip(v, 0, 255).astype(np.uint8)
+    for v in (255, 250, 240, 200, 128, 30):
+        a = u8(v + rng.integers(-1, 2, (H, W)))
+        yield "flat %d, both +-1 noise" % v, a, u8(a.astype(int) + rng.integers(-1, 2, (H, W)))
+        a = np.full((H, W), v, np.uint8)
+        yield "flat %d vs +-2 noise" % v, a, u8(a.astype(int) + rng.integers(-2, 3, (H, W)))
+    a = u8(180 + 70 * xx / W + rng.integers(-1, 2, (H, W)))
+    yield "bright gradient", a, u8(a.astype(int) + rng.integers(-3, 4, (H, W)))
+    a = u8(np.where(((xx // 32) + (yy // 32)) % 2 == 0, 255, 235))
+    yield "bright checker, 32 px", a, u8(a.astype(int) + rng.integers(-2, 3, (H, W)))
+    a = u8(255 - ((xx * 7 + yy * 3) % 5))
+    yield "saturated sawtooth", a, u8(a.astype(int) - rng.integers(0, 3, (H, W)))
+    a = u8(245 + 8 * np.sin(xx / 3.0) * np.cos(yy / 5.0))
+    yield "bright ripple", a, u8(a.astype(int) + rng.integers(-1, 2, (H, W)))
+    yield "uncorrelated 250..255", u8(rng.integers(250, 256, (H, W))), u8(rng.integers(250, 256, (H, W)))
+    a = u8(rng.integers(0, 256, (H, W)))
+    yield "anti-correlated noise", a, u8(255 - a.astype(int))
+
+
+def adversarial():
+    """python tests/tools/fast_mode_model.py --adversarial: the table of profiles/r03_adversarial.md"""
+    import oracle
+    print("| image (384 x 512) | reference FMA vs exact: pixel / global | MODE_FAST vs FMA: pixel / global | MODE_FAST vs exact: pixel / global | MODE_SEPARABLE vs exact: pixel / global |")
+    print("|---|---|---|---|---|")
+    for name, a, b in adversarial_pairs():
+        fv, _, fmap = oracle.ssim_f32(a, b, want_map=True, threads=8)
+        nv, _, nmap = oracle.ssim_naive_f64(a, b, want_map=True, threads=8)
+        cells = ["%.2e / %.2e" % (np.abs(fmap.astype(f64) - nmap).max(), abs(float(fv) - nv))]
+        rf = evaluate(mode_fast, a, b, fv, fmap, nv, nmap)
+        rs = evaluate(mode_separable, a, b, fv, fmap, nv, nmap)
+        cells += ["%.2e / %.2e" % (rf[0], rf[1]), "%.2e / %.2e" % (rf[2], rf[3]), "%.2e / %.2e" % (rs[2], rs[3])]
+        print("| %s | %s |" % (name, " | ".join(cells)))
+
+
 def main():
     argv = sys.argv[1:]
+    if "--adversarial" in argv:
+        return adversarial()
     sets, jobs, forms = None, 8, []
     i = 0
     while i < len(argv):
