@@ -122,26 +122,25 @@ __device__ __forceinline__ V row_sum(V s0, V s1, V s2, V s3, V s4, V s5)
 // scatter "rows r-5..r+5 += sum5,sum4,..,sum0,..,sum5" (src/ssim_fma.cpp:246-257) becomes a
 // shift of the ring (3-address adds: the shift is free).  Every output row therefore receives
 // its 11 addends in source-row order, first one added to zero, exactly like the reference.
-template <bool FUSED, typename V>
+//
+// KMIN (warm-up rows only, round 3): while the strip's first ten source rows -- the ones above its first output row -- pass
+// through, ring entry k stands for an output row ABOVE the strip whenever k < 10 - i (i = 0..9 the warm-up row), and nothing
+// ever reads it: the scatter into entries below KMIN is skipped, and with it every row sum S_j that only those entries use
+// (the compiler drops them as dead).  Entries that will become outputs of the strip receive exactly what they always did.
+template <bool FUSED, int KMIN = 0, typename V>
+__device__ __forceinline__ void ring_scatter(V (&acc)[11], const V (&S)[6])
+{
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+        if (k >= KMIN) acc[k] = S[k < 5 ? 5 - k : k - 5] + acc[k + 1];
+    acc[10] = S[5];
+}
+template <bool FUSED, int KMIN = 0, typename V>
 __device__ __forceinline__ void blur_exact(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5)
 {
-    const V S0 = row_sum<0, FUSED>(s0, s1, s2, s3, s4, s5);
-    const V S1 = row_sum<1, FUSED>(s0, s1, s2, s3, s4, s5);
-    const V S2 = row_sum<2, FUSED>(s0, s1, s2, s3, s4, s5);
-    const V S3 = row_sum<3, FUSED>(s0, s1, s2, s3, s4, s5);
-    const V S4 = row_sum<4, FUSED>(s0, s1, s2, s3, s4, s5);
-    const V S5 = row_sum<5, FUSED>(s0, s1, s2, s3, s4, s5);
-    acc[0] = S5 + acc[1];
-    acc[1] = S4 + acc[2];
-    acc[2] = S3 + acc[3];
-    acc[3] = S2 + acc[4];
-    acc[4] = S1 + acc[5];
-    acc[5] = S0 + acc[6];
-    acc[6] = S1 + acc[7];
-    acc[7] = S2 + acc[8];
-    acc[8] = S3 + acc[9];
-    acc[9] = S4 + acc[10];
-    acc[10] = S5;
+    const V S[6] = {row_sum<0, FUSED>(s0, s1, s2, s3, s4, s5), row_sum<1, FUSED>(s0, s1, s2, s3, s4, s5), row_sum<2, FUSED>(s0, s1, s2, s3, s4, s5),
+                    row_sum<3, FUSED>(s0, s1, s2, s3, s4, s5), row_sum<4, FUSED>(s0, s1, s2, s3, s4, s5), row_sum<5, FUSED>(s0, s1, s2, s3, s4, s5)};
+    ring_scatter<FUSED, KMIN>(acc, S);
 }
 
 // acc[k] = h * g + acc[k+1]: the ring step of the separable blur.  In fp32 the packed FMA only exists in
@@ -180,7 +179,7 @@ template <int ORDER> __device__ constexpr int tap_at(int k)
     return ORDER == ORDER_CENTRE_FIRST ? k : ORDER == ORDER_SMALL_FIRST ? 5 - k : (k < 3 ? 2 - k : k);
 }
 
-template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
+template <int ORDER = ORDER_CENTRE_FIRST, int KMIN = 0, typename V, typename G>
 __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V s3, V s4, V s5, const G (&g)[6])
 {
     const V s[6] = {s0, s1, s2, s3, s4, s5};
@@ -188,16 +187,9 @@ __device__ __forceinline__ void blur_separable(V (&acc)[11], V s0, V s1, V s2, V
 #pragma unroll
     for (int k = 1; k < 6; ++k)
         h = fma_(s[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), h);
-    acc[0] = ring_fma(h, g[5], acc[1]);
-    acc[1] = ring_fma(h, g[4], acc[2]);
-    acc[2] = ring_fma(h, g[3], acc[3]);
-    acc[3] = ring_fma(h, g[2], acc[4]);
-    acc[4] = ring_fma(h, g[1], acc[5]);
-    acc[5] = ring_fma(h, g[0], acc[6]);
-    acc[6] = ring_fma(h, g[1], acc[7]);
-    acc[7] = ring_fma(h, g[2], acc[8]);
-    acc[8] = ring_fma(h, g[3], acc[9]);
-    acc[9] = ring_fma(h, g[4], acc[10]);
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+        if (k >= KMIN) acc[k] = ring_fma(h, g[k < 5 ? 5 - k : k - 5], acc[k + 1]);       // KMIN: see ring_scatter
     acc[10] = h * VT<V>::splat(g[5]);
 }
 
@@ -215,24 +207,26 @@ __device__ __forceinline__ void separable_rows_pair(V& hA, V& hB, const V (&a)[6
         hB = fma_(b[tap_at<ORDER>(k)], VT<V>::splat(g[tap_at<ORDER>(k)]), hB);
     }
 }
-template <typename V, typename G>
+template <int KMIN = 0, typename V, typename G>
 __device__ __forceinline__ void separable_columns_pair(V (&accA)[11], V (&accB)[11], V hA, V hB, const G (&g)[6])
 {
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
         const int t = k < 5 ? 5 - k : k - 5;
-        accA[k] = ring_fma(hA, g[t], accA[k + 1]);
-        accB[k] = ring_fma(hB, g[t], accB[k + 1]);
+        if (k >= KMIN) {                           // KMIN: see ring_scatter
+            accA[k] = ring_fma(hA, g[t], accA[k + 1]);
+            accB[k] = ring_fma(hB, g[t], accB[k + 1]);
+        }
     }
     accA[10] = hA * VT<V>::splat(g[5]);
     accB[10] = hB * VT<V>::splat(g[5]);
 }
-template <int ORDER = ORDER_CENTRE_FIRST, typename V, typename G>
+template <int ORDER = ORDER_CENTRE_FIRST, int KMIN = 0, typename V, typename G>
 __device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11], const V (&a)[6], const V (&b)[6], const G (&g)[6])
 {
     V hA, hB;
     separable_rows_pair<ORDER>(hA, hB, a, b, g);
-    separable_columns_pair(accA, accB, hA, hB, g);
+    separable_columns_pair<KMIN>(accA, accB, hA, hB, g);
 }
 
 // Per-pixel SSIM, unfused fp32 exactly as src/ssim.cpp:681-693 / src/ssim_avx.cpp:342-352.
@@ -747,9 +741,10 @@ void ssim_strip2_kernel(const KArgs args)
     // entry of each stream alternate between two registers instead of being copied into place.
     // `phase`: ROW_WARMUP = one of the 10 rows above the strip's first output row (blur only, nothing finished
     // yet), ROW_MAIN = blur + output row r-5, ROW_LAST = ROW_MAIN without preparing any further row.
-    auto row = [&](const int r, auto slot, auto phase_tag) {
+    auto row = [&](const int r, auto slot, auto phase_tag, auto kmin_tag) {
         constexpr int cur = decltype(slot)::value;
         constexpr int phase = decltype(phase_tag)::value;
+        constexpr int KMIN = decltype(kmin_tag)::value;      // warm-up rows: ring entries below KMIN are not needed (ring_scatter)
         // One wave == one workgroup: wave_sync() only orders LDS accesses for the compiler.
         // LDS latency schedule of one row.  The compiler emits a full s_waitcnt lgkmcnt(0) drain whenever it
         // cannot count (more than 15 operations in flight, or at the loop header), so requests and first uses
@@ -785,17 +780,12 @@ void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FAST && !HYB && EARLY) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {       // the ring scatter of blur_exact, on row sums formed at fold time
-                f2 (&acc)[11] = accAB[c];
-                acc[0] = sab[c][5] + acc[1]; acc[1] = sab[c][4] + acc[2]; acc[2] = sab[c][3] + acc[3]; acc[3] = sab[c][2] + acc[4];
-                acc[4] = sab[c][1] + acc[5]; acc[5] = sab[c][0] + acc[6]; acc[6] = sab[c][1] + acc[7]; acc[7] = sab[c][2] + acc[8];
-                acc[8] = sab[c][3] + acc[9]; acc[9] = sab[c][4] + acc[10]; acc[10] = sab[c][5];
-            }
+            for (int c = 0; c < 2; ++c) ring_scatter<FUSED, KMIN>(accAB[c], sab[c]);      // on row sums formed at fold time
         } else if constexpr (!FAST && !HYB) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c) blur_exact<FUSED>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
+            for (int c = 0; c < 2; ++c) blur_exact<FUSED, KMIN>(accAB[c], ca[c], fa[c][0], fa[c][1], fa[c][2], fa[c][3], fa[c][4]);
         } else {
-            separable_columns_pair(accAB[0], accAB[1], hab[0], hab[1], gf);      // the row pass ran with the fold (fold_ab)
+            separable_columns_pair<KMIN>(accAB[0], accAB[1], hab[0], hab[1], gf);      // the row pass ran with the fold (fold_ab)
         }
         // (4) the (a*a,b*b) streams / MODE_SEPARABLE: the (a'*a' + b'*b', a'b') streams
         __builtin_amdgcn_sched_barrier(0);
@@ -805,13 +795,13 @@ void ssim_strip2_kernel(const KArgs args)
                 const int m = 6 + c;
                 const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
                          q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
-                blur_exact<FUSED>(accQ[c], wq[m], q1, q2, q3, q4, q5);
+                blur_exact<FUSED, KMIN>(accQ[c], wq[m], q1, q2, q3, q4, q5);
             }
             asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
         } else {
             const f2 s0[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
             const f2 s1[6] = {wq[7], wq[8] + wq[6], wq[9] + wq[5], wq[10] + wq[4], wq[11] + wq[3], wq[12] + wq[2]};
-            blur_separable_pair<ORDER_CENTRE_FIRST>(accQ[0], accQ[1], s0, s1, gf);
+            blur_separable_pair<ORDER_CENTRE_FIRST, KMIN>(accQ[0], accQ[1], s0, s1, gf);
             asm volatile("" :: "v"(wq[0]), "v"(wq[13]));
         }
         Px2 head;
@@ -826,7 +816,7 @@ void ssim_strip2_kernel(const KArgs args)
                 head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
             // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
             const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
-            blur_exact<FUSED>(accX, wxx[6], x1, x2, x3, x4, x5);
+            blur_exact<FUSED, KMIN>(accX, wxx[6], x1, x2, x3, x4, x5);
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -886,11 +876,20 @@ void ssim_strip2_kernel(const KArgs args)
     };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, ROW_WARMUP> Warm;
+    typedef std::integral_constant<int, 0> K0;
     int r = r_begin;
+    // The ten warm-up rows, in pairs (the two LDS slots): warm-up row i only feeds ring entries k >= 10 - i, so the first
+    // three pairs run with KMIN = 9, 7, 5 -- 22 % of the warm-up's arithmetic (a 64-row strip of a lone 4096^2 pair: -3 %
+    // of its time; an 8-row strip of a small image: -12 %) -- and the last two as they are (KMIN 3 and 1 would save 4 adds).
+    row(r, S0(), Warm(), std::integral_constant<int, 9>());     row(r + 1, S1(), Warm(), std::integral_constant<int, 9>());
+    row(r + 2, S0(), Warm(), std::integral_constant<int, 7>()); row(r + 3, S1(), Warm(), std::integral_constant<int, 7>());
+    row(r + 4, S0(), Warm(), std::integral_constant<int, 5>()); row(r + 5, S1(), Warm(), std::integral_constant<int, 5>());
+    r += 6;
 #pragma unroll 1
-    for (int i = 0; i < 5; ++i, r += 2) {
-        row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
-        row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
+    for (int i = 0; i < 2; ++i, r += 2) {
+        row(r, S0(), Warm(), K0());
+        row(r + 1, S1(), Warm(), K0());
     }
     // Main rows, one reduction cell at a time; only the image's last cell can be shorter.
     const int cell_rows = 1 << args.cell_shift;
@@ -900,11 +899,11 @@ void ssim_strip2_kernel(const KArgs args)
         const int rows = left < cell_rows ? left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
-            row(r, S0(), std::integral_constant<int, ROW_MAIN>());
-            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+            row(r, S0(), std::integral_constant<int, ROW_MAIN>(), K0());
+            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>(), K0());
         }
         if (rows & 1)
-            row(r, S0(), std::integral_constant<int, ROW_LAST>());
+            row(r, S0(), std::integral_constant<int, ROW_LAST>(), K0());
         cells.leaf[parked][lane] = (col_ok[0] ? colsum[0] : 0.0) + (col_ok[1] ? colsum[1] : 0.0);      // this cell's leaf of the lane
         colsum[0] = colsum[1] = 0.0;
         if (++parked == CELL_BATCH) {
@@ -1073,15 +1072,16 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     load_ab(0);
     fold_ab();
 
-    auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream) {
-        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED || (HYB && !decltype(mu_stream)::value)) blur_exact<FUSED>(acc, s0, s1, s2, s3, s4, s5);
+    auto blur = [&](auto& acc, auto s0, auto s1, auto s2, auto s3, auto s4, auto s5, auto mu_stream, auto kmin_tag) {
+        constexpr int KMIN = decltype(kmin_tag)::value;       // warm-up rows: see ring_scatter
+        if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED || (HYB && !decltype(mu_stream)::value)) blur_exact<FUSED, KMIN>(acc, s0, s1, s2, s3, s4, s5);
         else if constexpr (FAST || HYB)   // the same tap order as the two-column kernel: the two agree bit for bit
-            blur_separable<ORDER_CENTRE_FIRST>(acc, s0, s1, s2, s3, s4, s5, args.gf);
+            blur_separable<ORDER_CENTRE_FIRST, KMIN>(acc, s0, s1, s2, s3, s4, s5, args.gf);
         else  // fp64 internals: the folded sums are exact integers in fp32; everything after is double
-            blur_separable(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
+            blur_separable<ORDER_CENTRE_FIRST, KMIN>(acc, to_f64(s0), to_f64(s1), to_f64(s2), to_f64(s3), to_f64(s4), to_f64(s5), args.gd);
     };
 
-    auto row = [&](const idx_t r, auto slot, auto phase_tag) {
+    auto row = [&](const idx_t r, auto slot, auto phase_tag, auto kmin_tag) {
         constexpr int cur = decltype(slot)::value;
         constexpr int phase = decltype(phase_tag)::value;
         const Slot1& s = ring[cur];
@@ -1094,14 +1094,14 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
             if constexpr (!FOUR) wx[t] = s.x[base + t];
         }
         __builtin_amdgcn_sched_barrier(0);
-        blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4], std::true_type());
+        blur(accAB, ca, fa[0], fa[1], fa[2], fa[3], fa[4], std::true_type(), kmin_tag);
         __builtin_amdgcn_sched_barrier(0);
-        blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0], std::false_type());
+        blur(accQ, wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0], std::false_type(), kmin_tag);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (phase != ROW_LAST) load_ab(cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!FOUR)
-            blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type());
+            blur(accX, wx[5], wx[6] + wx[4], wx[7] + wx[3], wx[8] + wx[2], wx[9] + wx[1], wx[10] + wx[0], std::false_type(), kmin_tag);
         __builtin_amdgcn_sched_barrier(0);
 
         if constexpr (phase != ROW_WARMUP) {         // ring entry 0 is the finished output row y = r - 5
@@ -1141,11 +1141,18 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     };
     typedef std::integral_constant<int, 0> S0;
     typedef std::integral_constant<int, 1> S1;
+    typedef std::integral_constant<int, ROW_WARMUP> Warm;
+    typedef std::integral_constant<int, 0> K0;
     idx_t r = r_begin;
+    // warm-up pairs with KMIN = 9, 7, 5, then two unspecialised ones (see ssim_strip2_kernel)
+    row(r, S0(), Warm(), std::integral_constant<int, 9>());     row(r + 1, S1(), Warm(), std::integral_constant<int, 9>());
+    row(r + 2, S0(), Warm(), std::integral_constant<int, 7>()); row(r + 3, S1(), Warm(), std::integral_constant<int, 7>());
+    row(r + 4, S0(), Warm(), std::integral_constant<int, 5>()); row(r + 5, S1(), Warm(), std::integral_constant<int, 5>());
+    r += 6;
 #pragma unroll 1
-    for (int i = 0; i < 5; ++i, r += 2) {
-        row(r, S0(), std::integral_constant<int, ROW_WARMUP>());
-        row(r + 1, S1(), std::integral_constant<int, ROW_WARMUP>());
+    for (int i = 0; i < 2; ++i, r += 2) {
+        row(r, S0(), Warm(), K0());
+        row(r + 1, S1(), Warm(), K0());
     }
     const int cell_rows = 1 << args.cell_shift;
     uint32_t cell_y = (uint32_t)(y0 >> args.cell_shift), parked = 0;
@@ -1154,11 +1161,11 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         const int rows = left < cell_rows ? (int)left : cell_rows;
 #pragma unroll 1
         for (int i = rows >> 1; i > 0; --i, r += 2) {
-            row(r, S0(), std::integral_constant<int, ROW_MAIN>());
-            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>());
+            row(r, S0(), std::integral_constant<int, ROW_MAIN>(), K0());
+            row(r + 1, S1(), std::integral_constant<int, ROW_MAIN>(), K0());
         }
         if (rows & 1)
-            row(r, S0(), std::integral_constant<int, ROW_LAST>());
+            row(r, S0(), std::integral_constant<int, ROW_LAST>(), K0());
         cells.leaf[parked][lane] = col_ok ? colsum : 0.0;
         colsum = 0.0;
         if (++parked == CELL_BATCH) {
