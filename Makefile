@@ -49,9 +49,12 @@ $(OBJ)/ssim_dropin.o: $(SRC)/ssim_dropin.cpp $(SRC)/ssim_internal.h include/rmgr
 	@mkdir -p $(OBJ)
 	$(CXX) -std=c++98 -pedantic -O2 -fPIC -Wall -Wextra -Iinclude -c $< -o $@
 
-$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
+# Only the API leaves the shared libraries: $(SRC)/exports.map (the reference's archive exposes only its API as well).
+EXPORTS := -Wl,--version-script=$(SRC)/exports.map
+
+$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 
 # The reference's RMGR_SSIM_USE_DOUBLE build configuration (CMakeLists.txt:53, src/ssim_internal.h:26-37) as a second
 # flavour of the same library: identical kernels and drop-in layer, only the C ABI's default arithmetic differs (fp64
@@ -61,9 +64,9 @@ $(OBJ)/ssim_hip_abi_double.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h incl
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRMGR_SSIM_USE_DOUBLE=1 -x hip -c $< -o $@
 
-$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o
+$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 
 # The command-line tool: plain host C++ on top of the C ABI (reference: src/ssim-cli.cpp).
 $(BIN)/rmgr-ssim: $(SRC)/ssim_cli.cpp $(OUT)/librmgr-ssim-hip.so include/rmgr/ssim.h include/rmgr/ssim-hip.h

@@ -20,7 +20,8 @@
  *   rmgr_ssim_hip_set_mode             select_impl() / RMGR_SSIM_USE_DOUBLE   src/ssim.cpp:808-896, src/ssim_internal.h:26-37
  *
  * All functions return 0 or an errno value (EINVAL, ENOMEM, ECHILD = a HIP call failed,
- * ENODEV = no gfx950 device / extension not usable), exactly like the reference's API.
+ * ENODEV = no gfx950 device / extension not usable), exactly like the reference's API; the multi-GPU
+ * exchange (rmgr_ssim_hip_comm_*) adds ENOSYS = no librccl and ETIMEDOUT = a peer rank did not arrive in time.
  */
 #ifndef RMGR_SSIM_HIP_H
 #define RMGR_SSIM_HIP_H
@@ -173,9 +174,19 @@ rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uin
  * of per-image fp64 sums, then all ranks call comm_allreduce_sums on the whole vector: one RCCL
  * all-reduce(sum, fp64) over xGMI.  Adding zeros is exact, so the result does not depend on the GPU
  * count.  This is the GPU-era form of the reference's per-thread partials + final loop
- * (src/ssim.cpp:902-926, :1094-1100).  librccl.so is loaded on first use; ENOSYS if it is absent.
+ * (src/ssim.cpp:902-926, :1094-1100).  librccl is loaded on first use ($RMGR_SSIM_HIP_RCCL_LIB, else the
+ * copy already in the process or the system's); ENOSYS if it is absent.
  *   rank 0: comm_get_unique_id(id); ship the 128 bytes to the other ranks by any means (file, socket, MPI)
  *   all:    comm_init(ctx, id, rankCount, rank);  ...  comm_allreduce_sums(ctx, sumsDevice, count);
+ *
+ * Bounded failure.  Where the reference reports a failed worker as ECHILD (src/ssim.cpp:1094-1097), a rank that never
+ * arrives is reported here as ETIMEDOUT after $RMGR_SSIM_HIP_COMM_TIMEOUT_S seconds (default 30): get_unique_id and
+ * comm_init (library load, bootstrap, rendezvous), the enqueue inside comm_allreduce_sums, rmgr_ssim_hip_synchronize()
+ * on a context that owns a communicator (the queued collective's peers may never launch theirs), and comm_destroy all
+ * return by that deadline.  After ETIMEDOUT from anything but get_unique_id the communicator has been aborted
+ * (ncclCommAbort) and the context is back in its single-GPU state; comm_init may be called again.  The communicator is
+ * created non-blocking (ncclCommInitRankConfig) when the loaded RCCL offers it; $RMGR_SSIM_HIP_COMM_BLOCKING=1 asks for a
+ * blocking one (its init is still bounded, by a helper thread that is abandoned when it does not return).
  */
 #define RMGR_SSIM_HIP_COMM_ID_BYTES 128
 rmgr_int32_t rmgr_ssim_hip_comm_get_unique_id(unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES]) RMGR_NOEXCEPT;
@@ -183,6 +194,10 @@ rmgr_int32_t rmgr_ssim_hip_comm_init(rmgr_ssim_hip_Context* ctx, const unsigned 
                                      rmgr_int32_t rankCount, rmgr_int32_t rank) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context* ctx, double* sumsDevice, rmgr_uint32_t count) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+/* Ranks RCCL itself counts in the context's communicator (ncclCommCount); 0 when it has none. */
+rmgr_int32_t rmgr_ssim_hip_comm_rank_count(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* rankCount) RMGR_NOEXCEPT;
+/* Which RCCL was loaded (version, path), whether non-blocking init is available, the deadline in force; static storage. */
+const char* rmgr_ssim_hip_comm_describe(void) RMGR_NOEXCEPT;
 
 /* Blocks until everything enqueued on the context's stream has finished. */
 rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;

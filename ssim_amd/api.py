@@ -71,6 +71,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
     "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
+    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -129,6 +130,7 @@ def load_library(path=None):
         "rmgr_ssim_hip_comm_init": [vp, ctypes.c_char_p, i32, i32],
         "rmgr_ssim_hip_comm_allreduce_sums": [vp, vp, u32],
         "rmgr_ssim_hip_comm_destroy": [vp],
+        "rmgr_ssim_hip_comm_rank_count": [vp, ctypes.POINTER(i32)],
     }
     for name, args in sig.items():
         if path is None and os.environ.get("RMGR_SSIM_LIB") and not hasattr(lib, name):
@@ -138,6 +140,9 @@ def load_library(path=None):
         fn.restype = i32
     lib.rmgr_ssim_hip_describe.argtypes = [vp]
     lib.rmgr_ssim_hip_describe.restype = ctypes.c_char_p
+    if hasattr(lib, "rmgr_ssim_hip_comm_describe"):
+        lib.rmgr_ssim_hip_comm_describe.argtypes = []
+        lib.rmgr_ssim_hip_comm_describe.restype = ctypes.c_char_p
     if path is None:
         _lib = lib
     return lib
@@ -367,6 +372,19 @@ class Context(object):
 
     def comm_allreduce_sums(self, sums_dev_ptr, count):
         _check("rmgr_ssim_hip_comm_allreduce_sums", self.lib.rmgr_ssim_hip_comm_allreduce_sums(self.handle, sums_dev_ptr, count))
+
+    def comm_destroy(self):
+        _check("rmgr_ssim_hip_comm_destroy", self.lib.rmgr_ssim_hip_comm_destroy(self.handle))
+
+    def comm_rank_count(self):
+        """Ranks RCCL counts in this context's communicator (ncclCommCount); 0 without one."""
+        n = ctypes.c_int32(0)
+        _check("rmgr_ssim_hip_comm_rank_count", self.lib.rmgr_ssim_hip_comm_rank_count(self.handle, ctypes.byref(n)))
+        return n.value
+
+    @staticmethod
+    def comm_describe():
+        return load_library().rmgr_ssim_hip_comm_describe().decode()
 
     def synth_pair(self, a_ptr, a_stride, b_ptr, b_stride, width, height, seed):
         """Fill two device planes with the synthetic pair of SURVEY.md 8(d) (asynchronous on the context's stream)."""

@@ -10,11 +10,14 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -71,6 +74,8 @@ struct rmgr_ssim_hip_Context_ {
     double   prof_ms;
 
     ncclComm_t comm;          // RCCL communicator (rmgr_ssim_hip_comm_*), NULL until comm_init
+    bool       comm_nonblocking;   // created with ncclCommInitRankConfig(blocking = 0): calls may report "in progress"
+    int        comm_ranks;         // ncclCommCount of the communicator
 
     char describe[256];
     std::mutex lock;
@@ -482,6 +487,8 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
     return rc ? rc : sh.rc;
 }
 
+int comm_bounded_sync(rmgr_ssim_hip_Context* c);      // with the RCCL section below
+
 rmgr_ssim_hip_Context* g_default = NULL;
 int                    g_default_err = 0;
 std::once_flag         g_default_once;
@@ -553,6 +560,8 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->h_map[0] = c->h_map[1] = NULL; c->h_map_cap[0] = c->h_map_cap[1] = 0;
     c->map_ev[0] = c->map_ev[1] = NULL;
     c->comm = NULL;
+    c->comm_nonblocking = false;
+    c->comm_ranks = 0;
     c->profiling = false;
     c->prof_launches = 0;
     c->prof_ms = 0.0;
@@ -795,6 +804,7 @@ rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
     USE_DEVICE(c);
+    if (c->comm) return comm_bounded_sync(c);      // a collective may be queued: its peers might never arrive
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1123,31 +1133,63 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_
 }
 
 // ---- RCCL, loaded lazily so that single-GPU users carry no dependency on it ----
+//
+// Every step that can wait for something outside this process has a DEADLINE ($RMGR_SSIM_HIP_COMM_TIMEOUT_S, default
+// 30 s): loading the library, the bootstrap behind ncclGetUniqueId, the rendezvous of ncclCommInitRank, the enqueue of the
+// all-reduce, the teardown.  The reference turns a failed worker into a bounded ECHILD return (src/ssim.cpp:1094-1097);
+// the GPU-era counterpart of "a worker failed" is "a rank never arrived", and that must come back as an errno
+// (ETIMEDOUT) too, not as a hang.  Mechanics: the communicator is created NON-BLOCKING (ncclCommInitRankConfig,
+// blocking = 0), its state polled with ncclCommGetAsyncError and, past the deadline, torn down with ncclCommAbort; and
+// the calls that have no asynchronous form (dlopen, ncclGetUniqueId, ncclCommInitRank on an RCCL without the config entry
+// point) run on a helper thread the caller waits for with a timeout -- a helper that never returns is abandoned (the
+// process keeps one parked thread; nothing it owns lives on the caller's stack).
 namespace {
 
 struct Rccl {
     void* handle;
+    char  path[256];          // what dlopen() resolved (diagnostics: rmgr_ssim_hip_comm_describe)
+    int   version;
+    ncclResult_t (*GetVersion)(int*);
     ncclResult_t (*GetUniqueId)(ncclUniqueId*);
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*);     // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*);                               // optional
+    ncclResult_t (*CommAbort)(ncclComm_t);                                                      // optional
+    ncclResult_t (*CommFinalize)(ncclComm_t);                                                   // optional
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     ncclResult_t (*CommDestroy)(ncclComm_t);
 };
 
+template <typename F> void sym(void* h, const char* name, F& f) { f = reinterpret_cast<F>(dlsym(h, name)); }
+
+// Which librccl: $RMGR_SSIM_HIP_RCCL_LIB if set; else the SONAME first -- a process that already carries an RCCL (a host
+// framework that bundles its own copy next to its own HIP runtime, e.g. a PyTorch wheel) must get THAT copy back, not a
+// second RCCL bound to a second HIP runtime -- then the development name and ROCm's default location.
 Rccl* rccl()
 {
     static Rccl api;
     static std::once_flag once;
     std::call_once(once, []() {
         memset(&api, 0, sizeof(api));
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        const char* names[] = {getenv("RMGR_SSIM_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !api.handle; ++i)
-            api.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+            if (names[i] && names[i][0]) api.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (!api.handle) return;
-        api.GetUniqueId  = reinterpret_cast<ncclResult_t (*)(ncclUniqueId*)>(dlsym(api.handle, "ncclGetUniqueId"));
-        api.CommInitRank = reinterpret_cast<ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>(dlsym(api.handle, "ncclCommInitRank"));
-        api.AllReduce    = reinterpret_cast<ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>(dlsym(api.handle, "ncclAllReduce"));
-        api.CommDestroy  = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(api.handle, "ncclCommDestroy"));
-        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy) { dlclose(api.handle); api.handle = NULL; }
+        sym(api.handle, "ncclGetVersion", api.GetVersion);
+        sym(api.handle, "ncclGetUniqueId", api.GetUniqueId);
+        sym(api.handle, "ncclCommInitRank", api.CommInitRank);
+        sym(api.handle, "ncclCommInitRankConfig", api.CommInitRankConfig);
+        sym(api.handle, "ncclCommGetAsyncError", api.CommGetAsyncError);
+        sym(api.handle, "ncclCommAbort", api.CommAbort);
+        sym(api.handle, "ncclCommFinalize", api.CommFinalize);
+        sym(api.handle, "ncclCommCount", api.CommCount);
+        sym(api.handle, "ncclAllReduce", api.AllReduce);
+        sym(api.handle, "ncclCommDestroy", api.CommDestroy);
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.CommCount) { dlclose(api.handle); api.handle = NULL; return; }
+        if (api.GetVersion) (void)api.GetVersion(&api.version);
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(api.AllReduce), &info) && info.dli_fname) snprintf(api.path, sizeof(api.path), "%s", info.dli_fname);
     });
     return api.handle ? &api : NULL;
 }
@@ -1158,11 +1200,173 @@ int map_nccl(ncclResult_t r)
     case ncclSuccess:          return 0;
     case ncclInvalidArgument:
     case ncclInvalidUsage:     return EINVAL;
+    case ncclInProgress:       return ETIMEDOUT;     // only ever surfaces once a deadline has passed
     case ncclSystemError:
     case ncclUnhandledCudaError:
     case ncclInternalError:
     default:                   return ECHILD;
     }
+}
+
+typedef std::chrono::steady_clock Clock;
+
+double comm_timeout_s()
+{
+    if (const char* e = getenv("RMGR_SSIM_HIP_COMM_TIMEOUT_S")) {
+        const double v = atof(e);
+        if (v > 0.0) return v;
+    }
+    return 30.0;
+}
+
+Clock::time_point deadline_from_now(double seconds)
+{
+    return Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
+}
+
+// $RMGR_SSIM_HIP_COMM_DEBUG=1: the helper thread reports its steps on stderr (where a stalled bootstrap stalled).
+void comm_debug(const char* what, double seconds = -1.0)
+{
+    static const bool on = getenv("RMGR_SSIM_HIP_COMM_DEBUG") && atoi(getenv("RMGR_SSIM_HIP_COMM_DEBUG")) != 0;
+    if (!on) return;
+    if (seconds >= 0.0) fprintf(stderr, "[rmgr-ssim comm] %s (%.3f s)\n", what, seconds);
+    else                fprintf(stderr, "[rmgr-ssim comm] %s\n", what);
+    fflush(stderr);
+}
+
+double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// A job for the helper thread.  Everything the helper touches lives in this heap block (shared with the caller through a
+// shared_ptr), so a helper that outlives its caller's patience has nothing dangling to write to.
+struct CommJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done;                     // the helper has finished (under m)
+    bool abandoned;                // the caller has given up waiting (under m): whatever the helper still produces is the helper's to clean up
+    std::atomic<bool> cancel;      // the polling loop's view of `abandoned`
+    int rc;
+    // inputs
+    int device, rank_count, rank;
+    bool want_id, nonblocking_ok;
+    ncclUniqueId id;
+    // outputs
+    ncclComm_t comm;
+    bool nonblocking;
+    CommJob() : done(false), abandoned(false), cancel(false), rc(0), device(0), rank_count(0), rank(0), want_id(false), nonblocking_ok(true), comm(NULL), nonblocking(false) { memset(&id, 0, sizeof(id)); }
+};
+
+void comm_job_body(const std::shared_ptr<CommJob>& j)
+{
+    const Clock::time_point t0 = Clock::now();
+    int rc = 0;
+    comm_debug("helper: loading librccl");
+    Rccl* r = rccl();                                        // may load (and page in) half a gigabyte of library
+    comm_debug(r ? r->path : "helper: no usable librccl", seconds_since(t0));
+    if (!r) rc = ENOSYS;
+    else if (j->want_id) { rc = map_nccl(r->GetUniqueId(&j->id)); comm_debug("helper: ncclGetUniqueId returned", seconds_since(t0)); }
+    else if (hipSetDevice(j->device) != hipSuccess) { (void)hipGetLastError(); rc = ENODEV; }
+    else {
+        ncclResult_t res = ncclInvalidUsage;
+        bool tried_config = false;
+        if (j->nonblocking_ok && r->CommInitRankConfig && r->CommGetAsyncError && r->CommAbort) {
+            ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+            cfg.blocking = 0;
+            res = r->CommInitRankConfig(&j->comm, j->rank_count, j->id, j->rank, &cfg);
+            tried_config = (res == ncclSuccess || res == ncclInProgress);
+            comm_debug(tried_config ? "helper: ncclCommInitRankConfig(blocking = 0) accepted" : "helper: ncclCommInitRankConfig refused, falling back to ncclCommInitRank", seconds_since(t0));
+            if (tried_config) {
+                j->nonblocking = true;
+                for (;;) {                                   // the rendezvous proceeds on RCCL's own thread
+                    ncclResult_t state = ncclSuccess;
+                    const ncclResult_t g = r->CommGetAsyncError(j->comm, &state);
+                    if (g != ncclSuccess) { res = g; break; }
+                    if (state != ncclInProgress) { res = state; break; }
+                    if (j->cancel.load()) { res = ncclInProgress; break; }      // the caller's deadline passed
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+                comm_debug(res == ncclSuccess ? "helper: communicator ready" : res == ncclInProgress ? "helper: deadline passed, aborting the communicator" : "helper: init failed, aborting the communicator", seconds_since(t0));
+                if (res != ncclSuccess && j->comm) { (void)r->CommAbort(j->comm); j->comm = NULL; comm_debug("helper: ncclCommAbort returned", seconds_since(t0)); }
+            } else {
+                j->comm = NULL;                              // a config this RCCL does not take: the plain call below
+            }
+        }
+        if (!tried_config) { res = r->CommInitRank(&j->comm, j->rank_count, j->id, j->rank); comm_debug("helper: ncclCommInitRank returned", seconds_since(t0)); }
+        if (res != ncclSuccess) j->comm = NULL;
+        rc = map_nccl(res);
+    }
+    std::unique_lock<std::mutex> lk(j->m);
+    j->rc = rc;
+    j->done = true;
+    const bool orphan = j->abandoned && j->comm != NULL;     // finished after the caller left: nobody will ever own this communicator
+    lk.unlock();
+    j->cv.notify_all();
+    if (orphan) {
+        if (r && r->CommAbort) (void)r->CommAbort(j->comm);
+        j->comm = NULL;
+        comm_debug("helper: late communicator aborted", seconds_since(t0));
+    }
+}
+
+// Runs the job on a helper thread and waits for it until the deadline.  Past it the caller returns ETIMEDOUT AT ONCE: the
+// helper is told to give up -- its polling loop aborts the half-built communicator, which can itself take seconds while
+// RCCL's bootstrap thread winds down -- and is left to finish that on its own (detached; it owns everything it touches).
+int run_comm_job(const std::shared_ptr<CommJob>& j, double timeout_s)
+{
+    std::thread t;
+    try { t = std::thread(comm_job_body, j); } catch (...) { return EAGAIN; }
+    std::unique_lock<std::mutex> lk(j->m);
+    if (j->cv.wait_until(lk, deadline_from_now(timeout_s), [&] { return j->done; })) { lk.unlock(); t.join(); return j->rc; }
+    j->abandoned = true;
+    j->cancel.store(true);
+    lk.unlock();
+    t.detach();
+    return ETIMEDOUT;
+}
+
+// Waits for a non-blocking communicator's last call to leave the "in progress" state.
+int comm_wait_ready(Rccl* r, rmgr_ssim_hip_Context* c, ncclResult_t first)
+{
+    if (first != ncclInProgress) return map_nccl(first);
+    if (!c->comm_nonblocking || !r->CommGetAsyncError) return map_nccl(first);
+    const Clock::time_point deadline = deadline_from_now(comm_timeout_s());
+    for (;;) {
+        ncclResult_t state = ncclSuccess;
+        const ncclResult_t g = r->CommGetAsyncError(c->comm, &state);
+        if (g != ncclSuccess) return map_nccl(g);
+        if (state != ncclInProgress) return map_nccl(state);
+        if (Clock::now() > deadline) return ETIMEDOUT;
+        std::this_thread::yield();
+    }
+}
+
+void comm_abort(Rccl* r, rmgr_ssim_hip_Context* c);
+
+// rmgr_ssim_hip_synchronize() of a context that owns a communicator: the stream may hold an all-reduce whose peers never
+// launch theirs, and hipStreamSynchronize() would then wait forever.  Poll instead; past the deadline the communicator is
+// aborted (which releases the kernel that spins on the missing peers) and the caller gets ETIMEDOUT.
+int comm_bounded_sync(rmgr_ssim_hip_Context* c)
+{
+    const Clock::time_point deadline = deadline_from_now(comm_timeout_s());
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { (void)hipGetLastError(); return map_hip_error(e); }
+        if (Clock::now() > deadline) {
+            comm_abort(rccl(), c);
+            (void)hipStreamSynchronize(c->stream);           // the aborted collective's kernel exits
+            return ETIMEDOUT;
+        }
+        std::this_thread::yield();
+    }
+}
+
+void comm_abort(Rccl* r, rmgr_ssim_hip_Context* c)
+{
+    if (!c->comm) return;
+    if (r && r->CommAbort) (void)r->CommAbort(c->comm);
+    c->comm = NULL;               // without ncclCommAbort the handle is leaked rather than destroyed: ncclCommDestroy would wait for the peers
+    c->comm_nonblocking = false;
+    c->comm_ranks = 0;
 }
 
 } // namespace
@@ -1171,11 +1375,11 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_get_unique_id(unsigned char id[RMGR_S
 {
     static_assert(sizeof(ncclUniqueId) == RMGR_SSIM_HIP_COMM_ID_BYTES, "ncclUniqueId size");
     if (!id) return EINVAL;
-    Rccl* r = rccl();
-    if (!r) return ENOSYS;
-    ncclUniqueId u;
-    const int rc = map_nccl(r->GetUniqueId(&u));
-    if (rc == 0) memcpy(id, &u, sizeof(u));
+    std::shared_ptr<CommJob> j;
+    try { j = std::make_shared<CommJob>(); } catch (...) { return ENOMEM; }
+    j->want_id = true;
+    const int rc = run_comm_job(j, comm_timeout_s());
+    if (rc == 0) memcpy(id, &j->id, sizeof(j->id));
     return rc;
 }
 
@@ -1183,12 +1387,29 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_init(rmgr_ssim_hip_Context* c, const 
                                                 rmgr_int32_t rankCount, rmgr_int32_t rank) RMGR_NOEXCEPT
 {
     if (!c || !id || rankCount < 1 || rank < 0 || rank >= rankCount || c->comm) return EINVAL;
+    std::shared_ptr<CommJob> j;
+    try { j = std::make_shared<CommJob>(); } catch (...) { return ENOMEM; }
+    j->device = c->device;
+    j->rank_count = rankCount;
+    j->rank = rank;
+    if (const char* e = getenv("RMGR_SSIM_HIP_COMM_BLOCKING")) j->nonblocking_ok = atoi(e) == 0;
+    memcpy(&j->id, id, sizeof(j->id));
+    const int rc = run_comm_job(j, comm_timeout_s());
+    if (rc) return rc;
+    c->comm = j->comm;
+    c->comm_nonblocking = j->nonblocking;
+    c->comm_ranks = 0;
     Rccl* r = rccl();
-    if (!r) return ENOSYS;
-    USE_DEVICE(c);
-    ncclUniqueId u;
-    memcpy(&u, id, sizeof(u));
-    return map_nccl(r->CommInitRank(&c->comm, rankCount, u, rank));
+    int n = 0;
+    if (r && r->CommCount(c->comm, &n) == ncclSuccess) c->comm_ranks = n;
+    return 0;
+}
+
+extern "C" rmgr_int32_t rmgr_ssim_hip_comm_rank_count(const rmgr_ssim_hip_Context* c, rmgr_int32_t* rankCount) RMGR_NOEXCEPT
+{
+    if (!c || !rankCount) return EINVAL;
+    *rankCount = c->comm ? c->comm_ranks : 0;      // what RCCL itself reports for the communicator (ncclCommCount), 0 without one
+    return 0;
 }
 
 extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context* c, double* sumsDevice, rmgr_uint32_t count) RMGR_NOEXCEPT
@@ -1198,7 +1419,9 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context*
     Rccl* r = rccl();
     if (!r) return ENOSYS;
     USE_DEVICE(c);
-    return map_nccl(r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
+    const int rc = comm_wait_ready(r, c, r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
+    if (rc == ETIMEDOUT) comm_abort(r, c);         // the enqueue itself never completed: the communicator is gone
+    return rc;
 }
 
 extern "C" rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
@@ -1206,9 +1429,31 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* c) RMG
     if (!c) return EINVAL;
     if (!c->comm) return 0;
     Rccl* r = rccl();
-    const int rc = r ? map_nccl(r->CommDestroy(c->comm)) : ENOSYS;
+    if (!r) { c->comm = NULL; return ENOSYS; }
+    USE_DEVICE(c);
+    int rc = 0;
+    if (c->comm_nonblocking && r->CommFinalize) {
+        // ncclCommFinalize is the asynchronous half of the teardown; ncclCommDestroy then only frees
+        rc = comm_wait_ready(r, c, r->CommFinalize(c->comm));
+        if (rc == ETIMEDOUT) { comm_abort(r, c); return rc; }
+    }
+    const int rd = map_nccl(r->CommDestroy(c->comm));
     c->comm = NULL;
-    return rc;
+    c->comm_nonblocking = false;
+    c->comm_ranks = 0;
+    return rc ? rc : rd;
+}
+
+extern "C" const char* rmgr_ssim_hip_comm_describe(void) RMGR_NOEXCEPT
+{
+    static char text[384];
+    static std::mutex m;
+    std::lock_guard<std::mutex> lk(m);
+    Rccl* r = rccl();
+    if (!r) snprintf(text, sizeof(text), "rccl: not loadable (%s)", dlerror() ? "dlopen failed" : "no usable librccl");
+    else snprintf(text, sizeof(text), "rccl %d.%d.%d from %s; non-blocking init %s; deadline %.1f s", r->version / 10000, (r->version / 100) % 100, r->version % 100,
+                  r->path[0] ? r->path : "?", (r->CommInitRankConfig && r->CommGetAsyncError && r->CommAbort) ? "available" : "unavailable", comm_timeout_s());
+    return text;
 }
 
 extern "C" {

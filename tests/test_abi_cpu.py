@@ -33,6 +33,19 @@ def test_library_exports_everything_the_headers_declare(lib):
         assert hasattr(lib, name), "missing export " + name
 
 
+@pytest.mark.parametrize("name", ["librmgr-ssim-hip.so", "librmgr-ssim-hip-double.so"])
+def test_library_exports_nothing_but_the_api(name):
+    """The other direction: the dynamic symbol table holds the declared C functions and the reference's three non-inline
+    C++ entry points (include/rmgr/ssim.h:686, :713, src/ssim_internal.h:53) and NOTHING else -- the ssim_hip:: interface
+    between the ABI layer and the kernels, helper functions and the HIP fat-binary bookkeeping stay inside
+    (ssim_amd/csrc/exports.map).  The reference's archive exposes only its API as well."""
+    path = os.path.join(os.path.dirname(ssim_amd.LIB_PATH), name)
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if l.strip())
+    allowed = declared_c_functions() | set(ssim_amd.CXX_SYMBOLS)
+    assert exported == allowed, (sorted(exported - allowed), sorted(allowed - exported))
+
+
 def test_struct_layouts_match_reference_abi():
     # LP64 layout of include/rmgr/ssim.h:469-533 of the reference
     assert ctypes.sizeof(ssim_amd.Version) == 24
@@ -423,3 +436,21 @@ def test_cmake_consumer_links_the_reference_target_names(tmp_path, double):
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     out = subprocess.run(["ldd", str(tmp_path / "build" / "client")], capture_output=True, text=True).stdout
     assert ("librmgr-ssim-hip-double.so" if double else "librmgr-ssim-hip.so") in out, out
+
+
+def test_comm_entry_points_without_a_device(lib):
+    """The RCCL exchange's entry points resolve, validate their arguments, and -- with no GPU for RCCL to bootstrap on --
+    fail promptly with an errno instead of hanging (the deadline machinery is exercised on the GPU, tests/test_gpu_zz_rccl.py)."""
+    import time
+    text = ssim_amd.Context.comm_describe()
+    assert text.startswith("rccl"), text
+    n = ctypes.c_int32(7)
+    assert lib.rmgr_ssim_hip_comm_rank_count(None, ctypes.byref(n)) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_comm_init(None, b"\0" * 128, 1, 0) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_comm_allreduce_sums(None, None, 0) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_comm_destroy(None) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_comm_get_unique_id(None) == errno.EINVAL
+    if ssim_amd.device_count() == 0:
+        t = time.time()
+        rc = lib.rmgr_ssim_hip_comm_get_unique_id(ctypes.create_string_buffer(128))
+        assert rc in (errno.ECHILD, errno.ENODEV, errno.ENOSYS, errno.ETIMEDOUT) and time.time() - t < 40, rc

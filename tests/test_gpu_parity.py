@@ -468,16 +468,6 @@ def test_full_size_known_answers_and_properties(gpu_ctx, oracle, manifest):
             d.free()
 
 
-def test_native_rccl_exchange_single_rank():
-    """rmgr_ssim_hip_comm_*: the RCCL all-reduce of per-image sums behind the C ABI.  One GPU is all a
-    test box has: a 1-rank communicator must leave the sums bit-identical (what N ranks add is zeros).
-    Own process, no torch (see tools/rccl_selftest.py)."""
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "..", "tools", "rccl_selftest.py")],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "ok" in r.stdout.split(), (r.stdout[-500:], r.stderr[-1500:])
-
-
 @pytest.mark.parametrize("openmp", [False, True])
 @pytest.mark.parametrize("heap", [False, True])
 @pytest.mark.parametrize("want_map", [False, True])

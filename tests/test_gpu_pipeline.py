@@ -1,7 +1,7 @@
 """GPU: round-2 additions to the C ABI.
 
-* BASELINE.json configs[3] at full count (1024 x 1080p) with the 8-GPU sharding emulated on one device and the
-  native RCCL exchange (tests/tools/config4_selftest.py, own process);
+* BASELINE.json configs[3] at full count (1024 x 1080p): known answers, 40 pairs against the oracle, and the 8-GPU
+  sharding emulated on one device -- no communicator anywhere (the RCCL exchange is tests/test_gpu_zz_rccl.py);
 * the cell-based fp64 reduction: per-image sums bit-identical for any strip height, kernel variant, batch split;
 * the descriptor-table ring: different batches enqueued back to back without draining the stream;
 * the banded (pipelined) host-pointer call: value and map bit-identical to the device path, for every map layout;
@@ -27,11 +27,83 @@ def bits64(a):
     return np.ascontiguousarray(a, np.float64).view(np.uint64)
 
 
-def test_config4_1024_pairs_1080p_sharded_equals_single_batch():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "config4_selftest.py")],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ok" in r.stdout.split(), (r.stdout[-800:], r.stderr[-1500:])
-    print(r.stdout.strip().splitlines()[0])
+CONFIG4_KATS = (0x3f64bb1f, 0x3f64bbf6, 0x3f64bb30)      # the reference's FMA path on 1080p seeds 0x5EED, 0x5EEE, 0x5EEF
+
+
+def config4_checked_pairs(total):
+    """The pairs of the configs[3] batch that are compared with the oracle: both ends, every boundary of the 8-way shard
+    table (the last pair of one rank and the first of the next), and pseudo-randomly chosen ones in between: 40 in all."""
+    from ssim_amd import sharding
+    picks = {0, 1, 2, total - 1}
+    for first, last in sharding.split_batch(total, 8):
+        picks.update(i for i in (first - 1, first, last - 1, last) if 0 <= i < total)
+    rng = np.random.default_rng(0xC4)
+    while len(picks) < min(40, total):
+        picks.add(int(rng.integers(0, total)))
+    return sorted(picks)
+
+
+def test_config4_1024_pairs_1080p_sharded_equals_single_batch(gpu_ctx, oracle):
+    """BASELINE.json configs[3] at its stated size on ONE GPU and without any communicator: all 1024 synthetic 1920x1080
+    pairs (seeds 0x5EED + i) resident in HBM.
+      1. one batch of 1024 through rmgr_ssim_hip_enqueue_batch -> the per-image fp64 sums;
+      2. the reference's FMA-path known answers for pairs 0, 1, 2;
+      3. 40 pairs -- ends, all eight shard boundaries (127/128 ... 895/896), random picks -- against the ORACLE on the same
+         pixels: the device-generated images equal their host twins byte for byte, the global float is bit-equal, the fp64
+         sum agrees to 1e-13 relative (only the summation order differs, SURVEY.md A.3);
+      4. the 8-GPU run emulated: the 8 shards of sharding.split_batch, each enqueued as its own batch into ITS slice of one
+         zeroed double[1024] (what the other ranks would add in the all-reduce is exact zeros) == (1) bit for bit; likewise
+         an uneven 3-way split and a 5-way split at another strip height.
+    The RCCL all-reduce on top of (4) is tests/test_gpu_zz_rccl.py's business: nothing here can wait for a peer."""
+    from ssim_amd import sharding
+    W, H, total = 1920, 1080, 1024
+    ctx = gpu_ctx
+    imgs = ctx.alloc(2 * W * H * total)
+    single = ctx.alloc(8 * total)
+    try:
+        params = (ssim_amd.Params * total)()
+        for i in range(total):
+            a = imgs.ptr + 2 * W * H * i
+            ctx.synth_pair(a, W, a + W * H, W, W, H, synth.BASE_SEED + i)
+            params[i] = ssim_amd.make_params(W, H, a, 1, W, a + W * H, 1, W)
+        ctx.enqueue_batch(params, total, single.ptr)
+        ctx.synchronize()
+        s_single = single.download(np.float64, (total,))
+        res = ssim_amd.finalize(s_single, W, H)
+        for i, k in enumerate(CONFIG4_KATS):
+            assert int(res[i].view(np.uint32)) == k, "pair %d: 0x%08x, want 0x%08x" % (i, int(res[i].view(np.uint32)), k)
+        assert np.all(np.isfinite(res)) and res.min() > 0.88 and res.max() < 0.90, (res.min(), res.max())
+
+        threads = oracle.oracle_lib().oracle_max_threads()
+        checked = config4_checked_pairs(total)
+        assert {0, 127, 128, 895, 896, 1023} <= set(checked) and len(checked) >= 32
+        for i in checked:
+            ha, hb = oracle.synth_pair(W, H, synth.BASE_SEED + i)
+            base = imgs.ptr + 2 * W * H * i
+            assert np.array_equal(ctx.download(base, np.uint8, (H, W)), ha), "generator mismatch (A, pair %d)" % i
+            assert np.array_equal(ctx.download(base + W * H, np.uint8, (H, W)), hb), "generator mismatch (B, pair %d)" % i
+            ov, osum, _ = oracle.ssim_f32(ha, hb, threads=threads)
+            assert f32_hex(res[i]) == f32_hex(ov), "pair %d: GPU %s, oracle %s" % (i, f32_hex(res[i]), f32_hex(ov))
+            assert abs(s_single[i] - osum) <= 1e-13 * abs(osum), (i, s_single[i], osum)
+
+        for world, strip_rows in ((8, 0), (3, 0), (5, 64)):
+            ctx.set_tuning(strip_rows, 0)
+            vec = ctx.alloc(8 * total).upload(np.zeros(total, np.float64))
+            try:
+                for first, last in sharding.split_batch(total, world):
+                    if last > first:
+                        shard = (ssim_amd.Params * (last - first))(*[params[i] for i in range(first, last)])
+                        ctx.enqueue_batch(shard, last - first, vec.ptr + 8 * first)
+                ctx.synchronize()
+                s_sharded = vec.download(np.float64, (total,))
+            finally:
+                vec.free()
+                ctx.set_tuning(0, 0)
+            bad = np.flatnonzero(bits64(s_sharded) != bits64(s_single))
+            assert bad.size == 0, "%d-way split: %d of %d sums differ from the single batch (first at %d)" % (world, bad.size, total, bad[0])
+    finally:
+        single.free()
+        imgs.free()
 
 
 def test_synth_generator_matches_host_twins(gpu_ctx, oracle):

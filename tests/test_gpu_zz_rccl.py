@@ -1,0 +1,65 @@
+"""GPU: the native RCCL exchange (rmgr_ssim_hip_comm_*), LAST in the suite on purpose.
+
+Everything in here depends on a communication library's bootstrap (sockets, topology discovery, a half-gigabyte
+shared object) on top of the GPU, i.e. on the box as much as on this repository -- so these tests are collected after
+every parity test (file name + the `rccl` marker handled in conftest.py), each runs tools/rccl_selftest.py in its OWN
+process with a hard limit of a minute, and a failure carries the stage markers and RCCL's INIT / BOOTSTRAP / NET log
+of the child, so that a red run says where it stopped.  The child enforces its own limit (faulthandler watchdog) and
+is killed by the parent -- never re-exec'd -- if even that fails.  No parity test depends on anything in this file.
+"""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu, pytest.mark.rccl]
+
+TOOL = os.path.join(ROOT, "tools", "rccl_selftest.py")
+
+
+def run_selftest(*args, limit=50, comm_timeout=None):
+    env = dict(os.environ, NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,BOOTSTRAP,NET", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               RCCL_SELFTEST_LIMIT_S=str(limit))
+    if comm_timeout is not None:
+        env["RMGR_SSIM_HIP_COMM_TIMEOUT_S"] = str(comm_timeout)
+    try:
+        r = subprocess.run([sys.executable, TOOL] + list(args), capture_output=True, text=True, timeout=limit + 10, env=env)
+    except subprocess.TimeoutExpired as e:       # the child's own watchdog did not fire: subprocess.run() has killed it
+        out = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
+        pytest.fail("rccl_selftest %s did not finish in %d s and was killed.\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
+                    % (" ".join(args), limit + 10, out[-1500:], err[-6000:]))
+    assert r.returncode == 0 and "RESULT ok" in r.stderr, (
+        "rccl_selftest %s failed (exit %d).\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
+        % (" ".join(args), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
+    return r
+
+
+def test_native_rccl_exchange_single_rank():
+    """A 1-rank communicator on the system's RCCL, no torch in the process: sums unchanged bit for bit, RCCL counts one
+    rank, double init is EINVAL, destroy + re-init works."""
+    r = run_selftest("single")
+    print("\n".join(l for l in r.stderr.splitlines() if l.startswith("[rccl_selftest")))
+
+
+def test_comm_init_with_an_absent_peer_times_out_instead_of_hanging():
+    """Rank 1 of 2 whose rank 0 never calls comm_init: ETIMEDOUT within the deadline (5 s here), after which the context
+    still computes and still accepts a working communicator.  The reference's bounded failure of a worker
+    (ECHILD, src/ssim.cpp:1094-1097) carried over to the exchange step."""
+    run_selftest("absent-peer", comm_timeout=5)
+
+
+def test_config4_shards_through_the_native_allreduce():
+    """One rank's share of configs[3] (128 x 1080p) as 8 / 3 / 5 emulated shards + the all-reduce of the whole vector on a
+    1-rank communicator == the single batch, bit for bit (the communicator-free form of this comparison, at all 1024 pairs,
+    is tests/test_gpu_pipeline.py::test_config4_...)."""
+    run_selftest("shards")
+
+
+def test_native_rccl_exchange_inside_a_torch_process():
+    """The same 1-rank exchange in a process that imported torch first: the library must pick up the RCCL (and HIP runtime)
+    already in the process -- torch's bundled copies -- which is the configuration of `bench.py --exchange native`."""
+    run_selftest("single", "--with-torch", limit=110)
