@@ -14,7 +14,12 @@ else (RANK / LOCAL_RANK / WORLD_SIZE set) it is simply one of the ranks.
 A "step" is one pass of the hot path over one batch: distinct synthetic pairs (seeds 0x5EED+i,
 SURVEY.md 8(d)) resident in HBM, one batched launch per rank through the C ABI
 (rmgr_ssim_hip_enqueue_batch), and -- for N > 1 -- one RCCL all-reduce of the per-image fp64 sums so
-that every rank holds every result.  Images are sharded by rank:
+that every rank holds every result.  That all-reduce is the PRODUCT's (`--exchange native`:
+rmgr_ssim_hip_comm_allreduce_sums behind the C ABI; torch.distributed only launches the ranks, hands
+rank 0's communicator id around and takes the max of the elapsed times) whenever its communicator comes
+up on every rank within its deadline -- the default, `auto`, otherwise falls back to
+torch.distributed.all_reduce and says so in `exchange` (carrier, ranks RCCL counted, all-reduce time per
+step, and that the other carrier delivers the same bits).  Images are sharded by rank:
     --scaling weak   (default) every rank owns PAIRS pairs: per-GPU work is fixed;
     --scaling strong the workload's total batch (e.g. BASELINE.json configs[3]: 1024 x 1080p) is split
                      over the ranks with sharding.split_batch: total work is fixed.
@@ -116,6 +121,23 @@ def host_cpu():
     return model, procs
 
 
+CPU_BASELINE_ENV = {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores", "OMP_DYNAMIC": "false"}
+
+
+def cpu_baseline_in_child(budget_s=10.0):
+    """Runs cpu_baseline() in a CHILD process (never exec: this process has initialised the GPU) whose OpenMP runtime starts
+    with its threads pinned -- OMP_PROC_BIND=close, OMP_PLACES=cores: one thread per physical core, neighbouring cores
+    first -- because the OpenMP runtime reads those variables once, when it is loaded, and this process loaded one long
+    ago (torch).  Unpinned, the 64-thread baseline varied 1.9x between its best and its median run (round 3)."""
+    env = dict(os.environ)
+    env.update(CPU_BASELINE_ENV)
+    env.pop("OMP_NUM_THREADS", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(budget_s)], env=env, stdout=subprocess.PIPE, timeout=600)
+    if r.returncode != 0:
+        raise SystemExit("the cpu_baseline child failed (exit %d)" % r.returncode)
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
 def cpu_baseline(budget_s=10.0):
     """Reference FMA+OpenMP path (or the port) on this box's host cores.  Headline: one 4096^2 pair, global only,
     all threads (the reference caps its pool at 64, src/ssim.cpp:1025), repeated for ~budget_s; plus, per BASELINE
@@ -125,11 +147,11 @@ def cpu_baseline(budget_s=10.0):
     if oracle.have_ref():
         kind = "reference"
         cores = min(oracle.ref_lib().ref_max_threads(), 64)
-        run = lambda a, b, threads, want_map=False: oracle.ref_ssim(a, b, want_map=want_map, impl=5, threads=threads)
+        run = lambda a, b, threads, want_map=False, out_map=None: oracle.ref_ssim(a, b, want_map=want_map, impl=5, threads=threads, out_map=out_map)
     else:
         kind = "port"
         cores = oracle.oracle_lib().oracle_max_threads()
-        run = lambda a, b, threads, want_map=False: oracle.ssim_f32(a, b, want_map=want_map, fused=True, threads=threads)
+        run = lambda a, b, threads, want_map=False, out_map=None: oracle.ssim_f32(a, b, want_map=want_map, fused=True, threads=threads, out_map=out_map)
 
     def timed(fn, budget, min_runs=3, max_runs=100000):
         ts = []
@@ -155,22 +177,26 @@ def cpu_baseline(budget_s=10.0):
     for name, (w, h, want_map, kat) in (("8k-map", (8192, 8192, True, WORKLOADS["8k-map"][5][0])),
                                         ("1080p", (1920, 1080, False, WORKLOADS["1080p"][5][0]))):
         aa, bb = oracle.synth_pair(w, h, 0x5EED)
-        r = run(aa, bb, cores, want_map)
+        mm = np.zeros((h, w), np.float32) if want_map else None      # one caller-owned map, touched once: as the reference's harness reuses its buffers
+        r = run(aa, bb, cores, want_map, mm)
         assert int(np.float32(r[0]).view(np.uint32)) == kat, "CPU baseline disagrees with the known answer (%s)" % name
-        ta = timed(lambda: run(aa, bb, cores, want_map), 2.0)
-        to = timed(lambda: run(aa, bb, 1, want_map), 0.0, min_runs=2 if name == "1080p" else 1)
+        ta = timed(lambda: run(aa, bb, cores, want_map, mm), 2.0)
+        to = timed(lambda: run(aa, bb, 1, want_map, mm), 0.0, min_runs=2 if name == "1080p" else 1)
         per[name] = {"pixels": w * h, "map": want_map, "threads_all_mpix_s": round(w * h / min(ta) / 1e6, 1),
                      "threads_all_median_mpix_s": round(w * h / statistics.median(ta) / 1e6, 1),
                      "one_thread_mpix_s": round(w * h / min(to) / 1e6, 1)}
-        del aa, bb, r
+        del aa, bb, r, mm
     model, procs = host_cpu()
+    pinning = ", ".join("%s=%s" % (k, os.environ[k]) for k in sorted(CPU_BASELINE_ENV) if os.environ.get(k)) or "unpinned"
     return {"value": round(px / min(ts) / 1e6, 1), "median": round(px / statistics.median(ts) / 1e6, 1), "unit": "Mpix/s",
-            "cores": cores, "kind": kind, "cpu_model": model, "logical_cpus": procs, "runs": len(ts),
+            "cores": cores, "threads": cores, "pinning": pinning, "best_over_median": round(statistics.median(ts) / min(ts), 3),
+            "kind": kind, "cpu_model": model, "logical_cpus": procs, "runs": len(ts),
             "one_thread_mpix_s": per["4k"]["one_thread_mpix_s"], "per_config": per,
-            "sample": "%d back-to-back runs of one 4096x4096 pair (seed 0x5EED, global only) over ~%.0f s on %d threads: value = best run, "
-                      "median = median run; per_config: best of ~2 s (all threads) / of 1-2 runs (1 thread) on one pair of each image size; %s"
-                      % (len(ts), budget_s, cores,
-                         "real reference FMA/AVX kernel objects (oracle/_ref) driven by the harness tile loop, OpenMP static schedule"
+            "sample": "%d back-to-back runs of one 4096x4096 pair (seed 0x5EED, global only) over ~%.0f s on %d threads (%s): value = best run, "
+                      "median = median run (the figure to quote); per_config: best of ~2 s (all threads) / of 1-2 runs (1 thread) on one pair of each image size; %s"
+                      % (len(ts), budget_s, cores, pinning,
+                         "the reference's real FMA/AVX kernel objects (oracle/_ref: src/ssim_fma.cpp, src/ssim_avx.cpp compiled as they are) driven by "
+                         "the tile loop of oracle/ref_harness.cpp -- NOT by src/ssim.cpp, which needs a cmake-generated header -- OpenMP static schedule over tiles"
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
@@ -336,11 +362,20 @@ def main():
     ap.add_argument("--mode", type=int, default=0, help="0 exact (default), 1 fast (reference-order E planes, separable mu), 2 double, 3 unfused, 4 separable")
     ap.add_argument("--strip-rows", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--exchange", choices=["auto", "native", "torch"], default="auto",
+                    help="N > 1: who carries the all-reduce of the per-image sums.  native = the product's own rmgr_ssim_hip_comm_* (RCCL behind "
+                         "the C ABI; rank 0's communicator id travels over the launcher's process group); torch = torch.distributed.all_reduce; "
+                         "auto (default) = native when its communicator comes up on every rank within the deadline, else torch -- the line says which")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
     ap.add_argument("--print-launch", action="store_true", help="print the rank launcher command for --gpus N and exit (no GPU needed)")
     ap.add_argument("--print-shards", action="store_true", help="print the shard table (JSON: which global pairs each rank owns) for --gpus N and exit (no GPU needed)")
+    ap.add_argument("--cpu-baseline-only", type=float, default=0.0, metavar="SECONDS",
+                    help="internal: time the CPU baseline for about SECONDS and print its JSON object (the child process of the default run)")
     args = ap.parse_args()
+    if args.cpu_baseline_only > 0:
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only)))
+        return 0
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.print_launch:
@@ -391,6 +426,34 @@ def main():
     ctx = ssim_amd.Context(local_rank, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
     ctx.set_tuning(args.strip_rows, args.variant)
 
+    # --- the exchange step's carrier.  The product's own is rmgr_ssim_hip_comm_*: rank 0 creates the
+    #     communicator id, the launcher's process group -- the control plane: barriers, the max over ranks of the elapsed
+    #     time -- carries its 128 bytes to the other ranks, and every rank joins with a DEADLINE (a rank that cannot
+    #     come up returns ETIMEDOUT instead of hanging the job; then, under `auto`, all ranks agree to use torch's). ---
+    exchange = {"carrier": "none", "ranks_seen": world if dist is None else None}
+    if dist is not None:
+        exchange = {"carrier": "torch", "requested": args.exchange, "ranks_seen": dist.get_world_size()}
+        if args.exchange in ("auto", "native"):
+            os.environ.setdefault("RMGR_SSIM_HIP_COMM_TIMEOUT_S", "60")
+            err = None
+            try:
+                uid = sharding.handoff_unique_id(dist, ssim_amd.Context.comm_unique_id, rank)
+                ctx.comm_init(uid, world, rank)
+            except Exception as e:       # noqa: BLE001 -- any failure of the native carrier is reported, never fatal under auto
+                err = "%s: %s" % (type(e).__name__, e)
+            if sharding.all_agree(dist, err is None, dev):
+                exchange.update({"carrier": "native", "ranks_seen": ctx.comm_rank_count(), "rccl": ssim_amd.Context.comm_describe()})
+                if exchange["ranks_seen"] != world:
+                    raise SystemExit("rank %d: RCCL counts %d ranks in the native communicator, the launcher started %d" % (rank, exchange["ranks_seen"], world))
+            else:
+                if err is None:
+                    ctx.comm_destroy()
+                exchange["native_error"] = err or "another rank's communicator did not come up"
+                sys.stderr.write("bench.py rank %d: native exchange unavailable (%s)\n" % (rank, exchange["native_error"]))
+                if args.exchange == "native":
+                    raise SystemExit("--exchange native: %s" % exchange["native_error"])
+    native = exchange["carrier"] == "native"
+
     W, H, weak_pairs, strong_total, want_map, kats, workload_desc = WORKLOADS[args.workload]
     # --- shard the batch by image: rank r owns global pairs [first, last) ---
     table = shard_table(args, world)
@@ -403,11 +466,23 @@ def main():
     work = torch.zeros_like(sums_all)
     my_slice_ptr = sums_all.data_ptr() + 8 * first
 
-    def step():
+    ex_events = []                       # (begin, end) HIP events around the exchange of each timed step
+
+    def step(timed=False, carrier=None):
         if mine:
             ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
+        if dist is None:
+            return sums_all
         # all-reduce of the per-image partial sums; other ranks contribute exact zeros
-        return sharding.exchange_sums(sums_all, work, dist)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        use_native = native if carrier is None else carrier == "native"
+        out = sharding.exchange_sums_native(ctx, sums_all, work) if use_native else sharding.exchange_sums(sums_all, work, dist)
+        if timed:
+            e1.record()
+            ex_events.append((e0, e1))
+        return out
 
     def fence():
         torch.cuda.synchronize()
@@ -449,7 +524,7 @@ def main():
     ctx.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
@@ -464,6 +539,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the exchange as the stream saw it: copy of the vector + the all-reduce, INCLUDING the wait for the slowest rank
+        ex_ms = sorted(a.elapsed_time(b) for a, b in ex_events)
+        exchange.update({"allreduce_ms_per_step": round(sum(ex_ms) / max(len(ex_ms), 1), 4), "allreduce_ms_median": round(ex_ms[len(ex_ms) // 2], 4) if ex_ms else None,
+                         "allreduce_note": "HIP events around the exchange (vector copy + all-reduce of %d doubles) of every timed step on rank 0: includes waiting for the slowest rank's kernels" % total})
+        # the carrier that was NOT timed must deliver the same vector, bit for bit (untimed)
+        if native:
+            chk = step(carrier="torch")
+            fence()
+            if not np.array_equal(chk.cpu().numpy().view(np.uint64), full_bits):
+                raise SystemExit("rank %d: the torch exchange returned different sums than the native one" % rank)
+            exchange["crosscheck"] = "torch.distributed.all_reduce delivers the same vector bit for bit (untimed step)"
 
     # --- the two opt-in modes on the same batch (kernel time only; never `value`) ---
     other = {}
@@ -584,10 +670,12 @@ def main():
             "config": {"workload": "%s, %s, sharded by image, %s"
                                    % (workload_desc,
                                       "%d pairs per GPU per step" % mine if args.scaling == "weak" else "%d pairs in total split over %d GPUs (%d on rank 0)" % (total, world, mine),
-                                      "RCCL all-reduce of per-image fp64 sums per step" if world > 1 else "single GPU, no collective"),
+                                      ("RCCL all-reduce of per-image fp64 sums per step (%s)" % ("rmgr_ssim_hip_comm_allreduce_sums behind the C ABI" if native else "torch.distributed"))
+                                      if dist is not None else "single GPU, no collective"),
                        "name": args.workload, "mode": MODE_NAMES[args.mode],
                        "pairs_per_gpu": mine, "pairs_total": total, "width": W, "height": H, "strip_rows": args.strip_rows, "variant": args.variant,
                        "results_digest": result_digest},
+            "exchange": exchange,
             "roofline": roof,
             "valu": valu,
             "single_pair": single,
@@ -597,7 +685,7 @@ def main():
             "device": ctx.describe(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline_in_child()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
     if dist is not None:

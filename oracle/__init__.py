@@ -109,7 +109,7 @@ def _views(img, step, stride):
 
 
 def ssim_f32(a, b, want_map=False, fused=True, threads=1, a_step=None, a_stride=None,
-             b_step=None, b_stride=None, width=None, height=None):
+             b_step=None, b_stride=None, width=None, height=None, out_map=None):
     """oracle fp32 SSIM of two uint8 arrays.  By default a, b are 2-D C-contiguous planes.
     Explicit step/stride (bytes) + width/height address pixel (x,y) at base + x*step + y*stride."""
     a = np.ascontiguousarray(a) if a_step is None else a
@@ -122,7 +122,10 @@ def ssim_f32(a, b, want_map=False, fused=True, threads=1, a_step=None, a_stride=
     b_stride = b.strides[0] if b_stride is None else b_stride
     out = ctypes.c_float()
     s = ctypes.c_double()
-    m = np.empty((h, w), np.float32) if want_map else None
+    if out_map is not None:
+        assert out_map.shape == (h, w) and out_map.dtype == np.float32 and out_map.flags.c_contiguous
+        want_map = True
+    m = (out_map if out_map is not None else np.empty((h, w), np.float32)) if want_map else None
     rc = oracle_lib().oracle_ssim_f32(ctypes.byref(out), ctypes.byref(s), w, h,
                                       _addr(a), a_step, a_stride, _addr(b), b_step, b_stride,
                                       _addr(m) if want_map else None, 1, w, int(fused), threads)
@@ -146,14 +149,18 @@ def ssim_naive_f64(a, b, want_map=False, threads=1):
     return out.value, s.value, m
 
 
-def ref_ssim(a, b, want_map=False, impl=5, threads=1):
-    """REAL reference kernels (oracle/_ref).  impl 5 = FMA, 4 = AVX."""
+def ref_ssim(a, b, want_map=False, impl=5, threads=1, out_map=None):
+    """REAL reference kernels (oracle/_ref).  impl 5 = FMA, 4 = AVX.  out_map: write the map into this H x W float32 array
+    (timing loops: a fresh 268 MB array per call measures the kernel's page faults, not the path)."""
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     h, w = a.shape
     out = ctypes.c_float()
     s = ctypes.c_double()
-    m = np.empty((h, w), np.float32) if want_map else None
+    if out_map is not None:
+        assert out_map.shape == (h, w) and out_map.dtype == np.float32 and out_map.flags.c_contiguous
+        want_map = True
+    m = (out_map if out_map is not None else np.empty((h, w), np.float32)) if want_map else None
     rc = ref_lib().ref_compute_ssim(ctypes.byref(out), ctypes.byref(s), w, h,
                                     _addr(a), 1, a.strides[0], _addr(b), 1, b.strides[0],
                                     _addr(m) if want_map else None, 1, w, impl, threads)

@@ -2,9 +2,16 @@
 
 Pairs are independent, so rank r owns a contiguous block of the batch and no image data crosses
 xGMI.  The only exchange is the per-image fp64 sums: every rank writes its own slice of a
-zero-initialised vector and one all-reduce (RCCL over xGMI with backend "nccl"; gloo in the CPU
-tests) gives every rank every sum.  Adding zeros is exact, so the result is bit-identical for any
-GPU count.  This replaces the per-thread partials + final loop of src/ssim.cpp:902-926, :1094-1100.
+zero-initialised vector and one all-reduce gives every rank every sum.  Adding zeros is exact, so
+the result is bit-identical for any GPU count.  This replaces the per-thread partials + final loop
+of src/ssim.cpp:902-926, :1094-1100.
+
+Two carriers for that all-reduce (bench.py --exchange):
+  native  the product's own: rmgr_ssim_hip_comm_allreduce_sums behind the C ABI (RCCL over xGMI,
+          include/rmgr/ssim-hip.h).  The launcher's process group is then only the control plane:
+          it hands rank 0's 128-byte communicator id to the other ranks (handoff_unique_id) and lets
+          the ranks agree on whether every communicator came up (all_agree).
+  torch   torch.distributed's all_reduce (backend "nccl" = torch's bundled RCCL; gloo in the CPU tests).
 """
 
 
@@ -36,3 +43,39 @@ def exchange_sums(sums_all, work, dist):
     dist.all_reduce(work)
     return work
 
+
+
+def handoff_unique_id(dist, make_id, rank):
+    """The id hand-off of the native exchange: rank 0 calls `make_id()` (rmgr_ssim_hip_comm_get_unique_id: 128 bytes),
+    every rank returns rank 0's bytes.  Carried by the already-initialised process group (any backend); a rank-0 failure
+    reaches every rank as the same exception instead of leaving the others waiting."""
+    box = [None]
+    if rank == 0:
+        try:
+            uid = bytes(make_id())
+            if len(uid) != 128:
+                raise ValueError("communicator id of %d bytes" % len(uid))
+            box[0] = ("id", uid)
+        except Exception as e:           # noqa: BLE001 -- shipped to the other ranks, re-raised below on all of them
+            box[0] = ("error", "%s: %s" % (type(e).__name__, e))
+    dist.broadcast_object_list(box, src=0)
+    kind, payload = box[0]
+    if kind != "id":
+        raise RuntimeError("rank 0 could not create the communicator id: %s" % payload)
+    return payload
+
+
+def all_agree(dist, ok, device=None):
+    """True on every rank iff `ok` is true on every rank (one MIN all-reduce of a flag on the process group)."""
+    import torch
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
+def exchange_sums_native(ctx, sums_all, work):
+    """The native carrier: `work` <- `sums_all` (zero outside this rank's slice), then the in-place RCCL all-reduce of
+    `work` through the C ABI on the context's stream.  Both tensors are float64 device tensors of the whole batch."""
+    work.copy_(sums_all)
+    ctx.comm_allreduce_sums(work.data_ptr(), work.numel())
+    return work

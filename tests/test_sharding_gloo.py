@@ -72,6 +72,54 @@ def test_strong_scaling_split_with_uneven_shares(tmp_path):
         assert np.array_equal(got.view(np.uint32), single.view(np.uint32)), r
 
 
+def handoff_worker(rank, world, port, out_dir, fail):
+    """The control plane of bench.py --exchange native on 2 CPU ranks (gloo): the id hand-off and the agreement step.  The id
+    itself is 128 random bytes here -- rmgr_ssim_hip_comm_get_unique_id needs a GPU -- what is under test is that every
+    rank ends up with RANK 0's bytes, that a failure on rank 0 reaches every rank as an exception (nobody is left waiting),
+    and that one rank's failed communicator makes ALL ranks fall back."""
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from ssim_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def make_id():
+        calls.append(rank)
+        if fail == "id":
+            raise OSError(110, "no librccl here")
+        return bytes([17 * (rank + 1)] * 64) + os.urandom(64)
+
+    try:
+        uid = sharding.handoff_unique_id(dist, make_id, rank)
+        outcome = "id:" + uid.hex()
+    except RuntimeError as e:
+        outcome = "error:" + str(e)
+    assert calls == ([0] if rank == 0 else []), calls           # only rank 0 creates the id
+    ok_here = not (fail == "init" and rank == 1)                # one rank's comm_init "timed out"
+    agreed = sharding.all_agree(dist, ok_here and outcome.startswith("id:"))
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%s\n%d\n" % (outcome, int(agreed)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", ["", "id", "init"])
+def test_native_exchange_id_handoff_and_agreement(tmp_path, fail):
+    import torch.multiprocessing as mp
+    world = 2
+    port = 33500 + (os.getpid() % 2000) + {"": 0, "id": 1, "init": 2}[fail]
+    mp.spawn(handoff_worker, args=(world, port, str(tmp_path), fail), nprocs=world, join=True)
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().split("\n") for r in range(world)]
+    assert got[0][0] == got[1][0], got                           # the same bytes -- or the same error -- on every rank
+    if fail == "id":
+        assert got[0][0].startswith("error:") and "no librccl here" in got[0][0]
+    else:
+        assert got[0][0].startswith("id:") and got[0][0][3:3 + 128] == "11" * 64       # rank 0's id, not rank 1's
+    assert got[0][1] == got[1][1] == ("1" if fail == "" else "0")       # native only if EVERY rank is up
+
+
 def test_bench_builds_its_own_rank_launcher():
     """`python bench.py --gpus N` must not depend on an outside launcher: it starts
     torch.distributed.run itself, as a child process, on 127.0.0.1."""
