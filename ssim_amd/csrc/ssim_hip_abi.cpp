@@ -36,8 +36,6 @@ struct rmgr_ssim_hip_Context_ {
 
     // grow-only device scratch
     double*   partials;     size_t partials_cap;   // doubles
-    uint32_t* tickets;      size_t tickets_cap;    // one zeroed counter per image of a launch: lets the strip kernel finish the images itself (ssim_kernels.h launch())
-    bool      fused_reduce;                        // $RMGR_SSIM_HIP_FUSED_REDUCE=0 keeps the separate reduction launch everywhere (A/B measurements)
     // Batch descriptor tables: a small ring of (device table, pinned mirror, "last launch that read it" event), so
     // that enqueueing a DIFFERENT batch never waits for the stream -- only for the launch kDescSlots enqueues ago --
     // and a serving loop that alternates between a few batches re-uses their uploaded tables.
@@ -266,15 +264,6 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
         geo.map_unit = descs[i].map != NULL && descs[i].map_step == 1;
     int rc = grow_device(c->partials, c->partials_cap, ssim_hip::partials_size(geo));
     if (rc) return rc;
-    // the image counters of the strip kernel's own reduction: zero when allocated, left zero by every launch that uses them
-    uint32_t* tickets = NULL;
-    if (reduce && c->fused_reduce && ssim_hip::strips_finish_images(geo, any_map)) {
-        if (count > c->tickets_cap) {
-            if ((rc = grow_device(c->tickets, c->tickets_cap, count))) return rc;
-            HIP_TRY(hipMemsetAsync(c->tickets, 0, sizeof(uint32_t) * c->tickets_cap, c->stream));
-        }
-        tickets = c->tickets;
-    }
     PairDesc single = descs[0];
     const PairDesc* descs_dev = NULL;
     int slot = -1;
@@ -286,10 +275,9 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     const bool launches_kernel = count > 0 && geo.strips_x > 0 && geo.strips_y > 0;
     hipEvent_t eb = NULL, ee = NULL;
     if (launches_kernel && (rc = acquire_events(c, eb, ee))) return rc;
-    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee, reduce, tickets);
+    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee, reduce);
     if (err != hipSuccess) {
         (void)hipGetLastError();
-        if (tickets) (void)hipMemsetAsync(c->tickets, 0, sizeof(uint32_t) * c->tickets_cap, c->stream);    // whatever state a failed launch left
         release_events(c, eb, ee);
         if (slot >= 0) { (void)hipStreamSynchronize(c->stream); c->desc_slots[slot].live = 0; }   // the table upload may still be queued
         return map_hip_error(err);
@@ -557,8 +545,6 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->strip_rows = 0;
     c->variant = 0;
     c->partials = NULL; c->partials_cap = 0;
-    c->tickets = NULL; c->tickets_cap = 0;
-    c->fused_reduce = !(getenv("RMGR_SSIM_HIP_FUSED_REDUCE") && atoi(getenv("RMGR_SSIM_HIP_FUSED_REDUCE")) == 0);
     memset(c->desc_slots, 0, sizeof(c->desc_slots));
     c->desc_next = 0;
     c->stage_a = NULL; c->stage_a_cap = 0;
@@ -599,7 +585,6 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
-    if (c->tickets) (void)hipFree(c->tickets);
     for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
         if (c->desc_slots[i].dev) (void)hipFree(c->desc_slots[i].dev);
         if (c->desc_slots[i].host) (void)hipHostFree(c->desc_slots[i].host);

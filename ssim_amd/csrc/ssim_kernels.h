@@ -118,14 +118,9 @@ size_t partials_size(const Geometry& geo);
 //   sums        device, count doubles: per-image fp64 sum of the SSIM values
 //   group       > 1 when every run of `group` consecutive descriptors addresses the interleaved channels of one
 //               image pair (interleaved_group()): scheduling hint only, results do not depend on it
-//   tickets     NULL, or device memory holding geo.count zeros: the strip kernel then finishes the images itself where that
-//               pays (strips_finish_images(): the last strip of an image to finish sums its cells; no reduction launch)
-//               and leaves the counters zero again.  The sums are the same bits either way.
 // ev_begin/ev_end (optional) are recorded around the main kernel only.
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true,
-                  uint32_t* tickets = nullptr);
-bool strips_finish_images(const Geometry& geo, bool map);
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true);
 
 // BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.
 hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,

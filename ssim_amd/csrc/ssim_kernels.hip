@@ -375,10 +375,6 @@ struct KArgs {
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
-    uint32_t        chunks;       // kReduceChunk-cell chunks per image when an image has more cells than that, else 0 (image_sum())
-    uint32_t*       tickets;      // non-NULL: the strip kernel also produces the per-image sums -- one counter per image of the launch, zero
-                                  // before and after it; the strip that draws the last ticket of its image sums the image's cells (image_finish())
-    double*         sums;         // [image] (with tickets)
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
     double          c1d, c2d;
@@ -482,21 +478,6 @@ struct CellBatch { double leaf[CELL_BATCH][64]; };
     } while (0)
 enum { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_HALF_MIRROR = 0x141 };
 
-// A cell partial leaves the wave as an AGENT-scope store (global_store ... sc1: written through this XCD's L2 to memory)
-// and is read back -- by ssim_reduce_kernel after the kernel boundary, or by the image's last strip inside this kernel
-// (image_finish()) -- with agent-scope loads.  The XCDs' L2s are not coherent with each other; with plain stores the
-// in-kernel hand-over would need an agent-scope release FENCE per strip, i.e. a write-back of the whole L2
-// (buffer_wbl2), which was measured at +23 us on a lone 4096^2 pair and -2 % on long launches.  Scoped accesses cost nothing
-// measurable: 8 B per 512 / 2048 pixels.
-__device__ __forceinline__ void store_partial(double* p, double v)
-{
-    __hip_atomic_store((gptr_f64)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_partial(const double* p)
-{
-    return __hip_atomic_load((gptr_f64)const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // The eight leaves of this lane's share of the batch, reduced as the balanced tree ((x0+x1)+(x2+x3))+((x4+x5)+(x6+x7)),
 // depth first and with the reads kept where they are used (fences): the kernels that run three waves per SIMD have
 // no registers to spare for eight doubles on top of their accumulator rings.
@@ -529,7 +510,7 @@ __device__ __forceinline__ void cell_batch_flush2(const KArgs& args, const Strip
     SSIM_DPP_ADD(t, DPP_QUAD_XOR2);            // 16 -> 32: the cell
     const uint32_t c = (uint32_t)lane >> 3, cx = 2u * st.sx + (((uint32_t)lane >> 2) & 1u);
     if ((lane & 3) == 0 && c < count && cx < args.cells_x)
-        store_partial(args.partials + ((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + cx, t);
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + cx] = t;
 }
 // one column per lane: a leaf is the lane's column, the wave is one cell wide.  Eight lanes share a 64-leaf tree
 // (whose first level adds the even/odd column pairs, as the two-column kernel does in registers).
@@ -543,86 +524,7 @@ __device__ __forceinline__ void cell_batch_flush1(const KArgs& args, const Strip
     SSIM_DPP_ADD(t, DPP_ROW_HALF_MIRROR);      // 32 -> 64 (quads are uniform: lane i <-> 7-i of each 8 is a lane of the other quad)
     const uint32_t c = (uint32_t)lane >> 3;
     if ((lane & 7) == 0 && c < count)
-        store_partial(args.partials + ((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + st.sx, t);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The per-image sum of the cell partials, in an order that depends on nothing but the number of cells (round 4: ONE
-// wavefront's order, so that the strip kernel itself can finish an image):
-//   chunk_sum(p, n), n <= kReduceChunk:  lane l adds p[l], p[l + 64], p[l + 128], ... in that order onto 0.0; then an xor
-//                                        butterfly over the 64 lanes (partner distance 32, 16, 8, 4, 2, 1: every lane ends
-//                                        with the same bits);
-//   image sum = chunk_sum(cells, count)                                         for images of up to kReduceChunk cells,
-//             = chunk_sum(the chunk_sums of consecutive kReduceChunk-cell chunks) for larger ones (8192^2: 4 chunks).
-// Two executors of the same definition: ssim_reduce_kernel (one wave per image and chunk, its own launch) and
-// image_finish() below (the last strip of an image to finish, inside the strip kernel).
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kReduceChunk = 8192;
-
-__device__ __forceinline__ double wave_butterfly(double acc)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        acc += __shfl_xor(acc, off, 64);
-    return acc;
-}
-
-// The loads are issued in blocks of up to 32 per lane before the first of them is consumed (the additions stay in index
-// order): the partials come from other XCDs' strips, i.e. from memory, and one round trip per element would make the
-// 128 elements per lane of a 4096^2 image cost ~100 us.
-__device__ __forceinline__ double chunk_sum(const double* __restrict__ p, uint32_t n, int lane)
-{
-    double acc = 0.0;
-    constexpr int kBlock = 32;
-    for (uint32_t base = 0; base < n; base += 64 * kBlock) {
-        double v[kBlock];
-#pragma unroll
-        for (int k = 0; k < kBlock; ++k) {
-            const uint32_t i = base + 64u * k + (uint32_t)lane;
-            v[k] = i < n ? load_partial(p + i) : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < kBlock; ++k) {
-            const uint32_t i = base + 64u * k + (uint32_t)lane;
-            acc = i < n ? acc + v[k] : acc;
-        }
-    }
-    return wave_butterfly(acc);
-}
-
-__device__ __forceinline__ double image_sum(const double* __restrict__ cells, uint32_t per_image, int lane, double* chunk_scratch)
-{
-    if (per_image <= kReduceChunk) return chunk_sum(cells, per_image, lane);
-    const uint32_t chunks = (per_image + kReduceChunk - 1) / kReduceChunk;
-    for (uint32_t c = 0; c < chunks; ++c) {
-        const uint32_t first = c * kReduceChunk, n = per_image - first < kReduceChunk ? per_image - first : kReduceChunk;
-        const double t = chunk_sum(cells + first, n, lane);
-        if (lane == 0) store_partial(chunk_scratch + c, t);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the wave's own (agent-scope) stores, read back by its other lanes
-    return chunk_sum(chunk_scratch, chunks, lane);
-}
-
-// Called by every strip after its last cell partial is stored (args.tickets != NULL).  The strips of an image draw tickets
-// from the image's counter; whoever draws the last one knows that every other strip's partials are in memory -- each strip
-// waits for its agent-scope stores to be acknowledged (s_waitcnt vmcnt(0)) BEFORE it draws its ticket, itself an
-// agent-scope atomic; see store_partial() for why this is not a pair of fences -- and sums the image's cells.
-// Saves the separate reduction launch: one kernel boundary on the latency of a single-pair call.
-__device__ __forceinline__ void image_finish(const KArgs& args, uint32_t img, uint32_t strips_per_image)
-{
-    const int lane = threadIdx.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t ticket = 0;
-    typedef uint32_t __attribute__((address_space(1)))* gptr_u32;
-    if (lane == 0) ticket = __hip_atomic_fetch_add((gptr_u32)args.tickets + img, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket + 1 != strips_per_image) return;
-    const uint32_t per_image = args.cells_x * args.cells_y;
-    const double total = image_sum(args.partials + (size_t)img * per_image, per_image, lane, args.partials + (size_t)args.count * per_image + (size_t)img * args.chunks);
-    if (lane == 0) {
-        ((gptr_f64)args.sums)[img] = total;
-        __hip_atomic_store((gptr_u32)args.tickets + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-    }
+        ((gptr_f64)args.partials)[((size_t)st.img * args.cells_y + cell_y_first + c) * args.cells_x + st.sx] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1016,7 +918,6 @@ void ssim_strip2_kernel(const KArgs args)
         wave_sync();
         cell_batch_flush2(args, st, cells, cell_y, parked);
     }
-    if (args.tickets) image_finish(args, st.img, args.strips_x * args.strips_y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1279,18 +1180,38 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         wave_sync();
         cell_batch_flush1(args, st, cells, cell_y, parked);
     }
-    if (args.tickets) image_finish(args, st.img, args.strips_x * args.strips_y);
 }
 
-// The separate executor of image_sum()'s definition: one wave per (image, chunk) -- grid (count, chunks) into the chunk sums,
-// then grid (count, 1) over those -- or grid (count, 1) straight into the sums for images of up to kReduceChunk cells.  Used
-// where the strip kernel does not finish the images itself (launch()).
-__global__ __launch_bounds__(64) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, uint32_t chunk, double* __restrict__ sums)
+// Per-image sum of the cell partials in a fixed order, so that the result depends on nothing but the image size:
+// thread t of 1024 adds partials t, t+1024, ... in that order; each wave then runs a fixed xor butterfly (every lane
+// ends with the same bits); the 16 wave totals are added in wave order.  Images with many cells (an 8192^2 pair has
+// 32768) are first cut into chunks of kReduceChunk cells, one block each (grid.y), then the chunk sums are summed the
+// same way.  One 4096^2 image: 8192 cells = 8 loads per thread (a single 256-thread tree took 8.7 us of a 96 us launch).
+constexpr uint32_t kReduceChunk = 8192;
+constexpr int      kReduceThreads = 1024;
+
+__global__ __launch_bounds__(kReduceThreads) void ssim_reduce_kernel(const double* __restrict__ partials, uint32_t per_image, uint32_t chunk, double* __restrict__ sums)
 {
+    __shared__ double sh[kReduceThreads / 64];
     const uint32_t first = blockIdx.y * chunk;
     const uint32_t n = per_image - first < chunk ? per_image - first : chunk;
-    const double t = chunk_sum(partials + (size_t)blockIdx.x * per_image + first, n, threadIdx.x);
-    if (threadIdx.x == 0) sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
+    const double* p = partials + (size_t)blockIdx.x * per_image + first;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n; i += kReduceThreads)
+        acc += p[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0)
+        sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0];
+#pragma unroll
+        for (int w = 1; w < kReduceThreads / 64; ++w)
+            t += sh[w];
+        sums[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = t;
+    }
 }
 
 template <int MODE>
@@ -1503,25 +1424,16 @@ hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hi
     if (per > kReduceChunk) {
         const uint32_t chunks = (per + kReduceChunk - 1) / kReduceChunk;
         double* chunk_sums = partials + (size_t)geo.count * per;
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(64), 0, stream, partials, per, kReduceChunk, chunk_sums);
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(64), 0, stream, chunk_sums, chunks, chunks, sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(kReduceThreads), 0, stream, partials, per, kReduceChunk, chunk_sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(kReduceThreads), 0, stream, chunk_sums, chunks, chunks, sums);
     } else {
-        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(64), 0, stream, partials, per, per, sums);
+        hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(kReduceThreads), 0, stream, partials, per, per, sums);
     }
     return hipGetLastError();
 }
 
-bool strips_finish_images(const Geometry& geo, bool map)
-{
-    // Where the strip kernel sums the images itself (image_finish()): launches without a map -- with one, the release fence
-    // of every strip would have to write the strip's share of the map back through L2 first -- whose images one wave sums
-    // quickly (at most a few chunks), and that compute something (an empty row window leaves the cells to the reduction).
-    const uint32_t per = geo.partials_per_image();
-    return !map && per > 0 && per <= 4 * kReduceChunk && geo.strips_x > 0 && geo.strips_y > 0;
-}
-
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce, uint32_t* tickets)
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce)
 {
     if (geo.count == 0) return hipSuccess;
     KArgs ka;
@@ -1535,11 +1447,6 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;
-    bool map = single.map != nullptr;   // for batches the ABI guarantees all-or-none and mirrors it into `single`
-    const bool fused = reduce && tickets != nullptr && strips_finish_images(geo, map);
-    ka.tickets = fused ? tickets : nullptr;
-    ka.sums = sums;
-    ka.chunks = geo.partials_per_image() > kReduceChunk ? (geo.partials_per_image() + kReduceChunk - 1) / kReduceChunk : 0;
     // c1, c2: products in double, then cast (src/ssim.cpp:956-960)
     ka.c1d = (0.01 * 255.0) * (0.01 * 255.0);
     ka.c2d = (0.03 * 255.0) * (0.03 * 255.0);
@@ -1557,6 +1464,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
             ka.gf[i] = (float)ka.gd[i];
         }
     }
+    bool map = single.map != nullptr;   // for batches the ABI guarantees all-or-none and mirrors it into `single`
     if (geo.strips_x == 0 || geo.strips_y == 0)
         return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
@@ -1575,7 +1483,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     }
     if (err != hipSuccess) return err;
     if (ev_end) { hipError_t e = hipEventRecord(ev_end, stream); if (e != hipSuccess) return e; }
-    return (reduce && !fused) ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
+    return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
 }
 
 } // namespace ssim_hip

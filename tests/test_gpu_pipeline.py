@@ -185,61 +185,6 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
             d.free()
 
 
-def test_strip_kernel_finishing_the_images_equals_the_separate_reduction(oracle):
-    """Round 4: where no map is written the strip that draws the last ticket of its image sums the image's cells inside the
-    strip kernel (ssim_kernels.hip image_finish()); elsewhere, and with $RMGR_SSIM_HIP_FUSED_REDUCE=0, ssim_reduce_kernel does
-    it in its own launch.  One definition, two executors: the per-image fp64 sums must be the same BITS -- on images whose
-    values make fp64 sums inexact, for cell counts below and above one 8192-cell chunk, for batches, repeated launches
-    (the counters must come back to zero), every kernel variant -- and the float must be the oracle's."""
-    saved = os.environ.get("RMGR_SSIM_HIP_FUSED_REDUCE")
-    try:
-        os.environ["RMGR_SSIM_HIP_FUSED_REDUCE"] = "1"
-        fused = ssim_amd.Context(0)
-        os.environ["RMGR_SSIM_HIP_FUSED_REDUCE"] = "0"
-        separate = ssim_amd.Context(0)
-    finally:
-        if saved is None:
-            os.environ.pop("RMGR_SSIM_HIP_FUSED_REDUCE", None)
-        else:
-            os.environ["RMGR_SSIM_HIP_FUSED_REDUCE"] = saved
-    rng = np.random.default_rng(404)
-    try:
-        #            w     h     pairs   (cells: 64 columns x 8 rows below 2048 rows, x 32 rows from there on)
-        for (w, h, n) in ((97, 41, 5), (640, 1000, 3), (2100, 2040, 2), (1300, 2100, 2), (4096, 4100, 1)):
-            pairs = hostile_pairs(rng, w, h, n)
-            for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_SEPARABLE, ssim_amd.MODE_DOUBLE):
-                for strip_rows, variant in ((0, 0), (0, 1), (64, 3), (8, 2)):
-                    got = {}
-                    for name, ctx in (("fused", fused), ("separate", separate)):
-                        keep = []
-                        ctx.set_mode(mode)
-                        ctx.set_tuning(strip_rows, variant)
-                        try:
-                            first = batch_sums(ctx, pairs, keep)
-                            again = batch_sums(ctx, pairs, keep)          # the counters were left at zero
-                            split = batch_sums(ctx, pairs, keep, [(0, 1), (1, n)]) if n > 1 else first
-                        finally:
-                            for d in keep:
-                                d.free()
-                        assert np.array_equal(bits64(first), bits64(again)) and np.array_equal(bits64(first), bits64(split)), (name, w, h, mode, strip_rows, variant)
-                        got[name] = first
-                    assert np.array_equal(bits64(got["fused"]), bits64(got["separate"])), (w, h, mode, strip_rows, variant, got["fused"] - got["separate"])
-            if w * h <= 1 << 22:
-                a, b = pairs[0]
-                fused.set_mode(ssim_amd.MODE_EXACT)
-                fused.set_tuning(0, 0)
-                keep = []
-                try:
-                    v = ssim_amd.finalize(batch_sums(fused, pairs[:1], keep), w, h)[0]
-                finally:
-                    for d in keep:
-                        d.free()
-                assert f32_hex(v) == f32_hex(oracle.ssim_f32(a, b, threads=oracle.oracle_lib().oracle_max_threads())[0]), (w, h)
-    finally:
-        fused.close()
-        separate.close()
-
-
 def test_different_batches_back_to_back(gpu_ctx, oracle):
     """Six different batches (more than the descriptor ring holds) enqueued without any synchronisation in between,
     then two of them alternating: every result must be the one of its own batch."""
