@@ -13,6 +13,7 @@
  *   rmgr_ssim_hip_compute_ssim_batch_host_devices  the same over several GPUs   src/ssim.cpp:1048-1088 (thread-pool dispatch)
  *   rmgr_ssim_hip_enqueue_batch        the caller-side loop over pairs    src/ssim-cli.cpp:197-210
  *                                      + per-thread fp64 partials         src/ssim.cpp:902-926
+ *   rmgr_ssim_hip_enqueue_rows / _reduce_cells   one image's tile jobs split over workers   src/ssim.cpp:1048-1100
  *   rmgr_ssim_hip_finalize             the final mean                     src/ssim.cpp:1090-1103
  *   rmgr_ssim_hip_compute_ssim_channels_host   the per-channel caller loop       src/ssim-cli.cpp:197-210, sample/rmgr-ssim-sample.cpp:82-101
  *   rmgr_ssim_hip_compute_ssim_luminance_host  RGB -> BT.601 Y, then SSIM        src/ssim-cli.cpp:145-195
@@ -48,6 +49,16 @@ extern "C" {
                                          reference's TEST tolerances against its double oracle (2e-6 / 1e-3) -- but not correlated with
                                          the reference's rounding, hence NOT guaranteed within 6.3e-4 of its FMA path per pixel */
 
+/* Version of THIS header's interface (the rmgr_ssim_hip_* functions and structs), independent of the reference API's
+ * 2.1.0 that rmgr_ssim_get_version() reports.  Bumped whenever a struct layout, a function signature or the meaning of a
+ * constant changes; rmgr_ssim_hip_get_abi_version() returns the value the LIBRARY was built with, so a client can
+ * refuse a mismatch at start-up.  History (INTEGRATION.md has the migration notes):
+ *   3  round 3: MODE_FAST (1) became the hybrid, the all-separable arithmetic moved to MODE_SEPARABLE (4); Plan grew by two fields
+ *   4  round 4: Plan carries structSize (first field) and the cell grid; rmgr_ssim_hip_comm_* calls are bounded by a deadline
+ *      (ETIMEDOUT), comm_rank_count / comm_describe added; row-band entry points (enqueue_rows, reduce_cells) added */
+#define RMGR_SSIM_HIP_ABI_VERSION 4
+rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT;
+
 /* An engine instance: one device, one stream, its own grow-only scratch.  A context may be used by one
  * host thread at a time (create one per thread, or serialise); the NULL / default context of the
  * host-pointer entry points is shared process-wide and locked internally. */
@@ -74,16 +85,24 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t s
 
 /* How a launch of `count` width x height pairs is cut into wavefront strips under the context's mode and
  * tuning (ctx may be NULL: default mode, default tuning, a 256-CU device).  Pure host arithmetic: no device
- * is touched.  The reference's counterpart is its 256x64 tile grid (src/ssim.cpp:1026-1028). */
+ * is touched.  The reference's counterpart is its 256x64 tile grid (src/ssim.cpp:1026-1028).
+ * The caller sets plan->structSize = sizeof(rmgr_ssim_hip_Plan) BEFORE the call; the library fills the fields that fit
+ * in that many bytes and nothing beyond them (EINVAL below RMGR_SSIM_HIP_PLAN_MIN_SIZE), so the struct can grow
+ * without overrunning the storage of a client compiled against an earlier header. */
 typedef struct rmgr_ssim_hip_Plan
 {
+    rmgr_uint32_t structSize;        /* in: sizeof(rmgr_ssim_hip_Plan) as the CALLER was compiled */
     rmgr_uint32_t stripWidth;        /* output columns per wavefront: 128 (two per lane) or 64 (one per lane: fp64 mode, tiny launches, tuning variant 1) */
     rmgr_uint32_t stripRows;         /* output rows per wavefront */
     rmgr_uint32_t stripsX, stripsY;  /* strips per image */
     rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count = workgroups of the launch */
+    /* -- RMGR_SSIM_HIP_PLAN_MIN_SIZE ends here -- */
     rmgr_uint32_t waveSlots;         /* wavefronts the device holds at a time with this kernel (SIMDs x waves per SIMD) */
     rmgr_uint32_t earlyRowSums;      /* 1: the bit-exact two-column kernel runs in its EARLY form (launches of <= 3 x waveSlots wavefronts) */
+    rmgr_uint32_t cellRows;          /* rows of a reduction cell (64 columns x cellRows rows): 8, or 32 for images of >= 2048 rows */
+    rmgr_uint32_t cellsX, cellsY;    /* the image's grid of reduction cells: cellsX * cellsY fp64 partials per image (rmgr_ssim_hip_enqueue_rows) */
 } rmgr_ssim_hip_Plan;
+#define RMGR_SSIM_HIP_PLAN_MIN_SIZE 24u
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT;
 
 /*
@@ -115,6 +134,28 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_device(rmgr_ssim_hip_Context* ctx, float
  */
 rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t count, const rmgr_ssim_Params* params,
                                          double* sumsDevice) RMGR_NOEXCEPT;
+
+/*
+ * ONE image pair cut into ROW BANDS -- for an image too large, or too urgent, for one GPU ("single huge
+ * image across GPUs"; the reference's counterpart is its tile grid walked by several threads, src/ssim.cpp:1048-1100).
+ * Everything device-resident and asynchronous on the context's stream.
+ *   rmgr_ssim_hip_enqueue_rows   computes output rows [yBegin, yBegin + yRows) of the pair (clipped to the image): the map
+ *       rows of the band, if params->ssimMap is set, and the band's reduction-cell partials -- 64 columns x cellRows rows
+ *       each, rmgr_ssim_hip_get_plan() reports cellRows / cellsX / cellsY -- into cellsDevice[cellY * cellsX + cellX], an
+ *       array of cellsX * cellsY doubles the caller ZEROED; cells outside the band are not touched.  yBegin must be a
+ *       multiple of cellRows and the band must end on one or at the last row (EINVAL otherwise).  The image pointers
+ *       describe the WHOLE image (topLeft = row 0), but only source rows yBegin - 5 ... yEnd + 4 (clamped to the image)
+ *       are read: a GPU that owns a band needs just those rows resident.
+ *   rmgr_ssim_hip_reduce_cells   sums `count` images' complete cell arrays ([image][cellY][cellX]) into sumsDevice[image]
+ *       in the fixed order every launch of this library uses.
+ * Bands may be computed by different contexts or GPUs into separate zeroed arrays; adding the arrays element-wise
+ * (rmgr_ssim_hip_comm_allreduce_sums on the cell array: every cell is non-zero on exactly one rank, and adding zeros is
+ * exact) and reducing the result gives the SAME BITS as one launch over the whole image on one GPU.
+ */
+rmgr_int32_t rmgr_ssim_hip_enqueue_rows(rmgr_ssim_hip_Context* ctx, const rmgr_ssim_Params* params, rmgr_uint32_t yBegin, rmgr_uint32_t yRows,
+                                        double* cellsDevice) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_reduce_cells(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count,
+                                        const double* cellsDevice, double* sumsDevice) RMGR_NOEXCEPT;
 
 /*
  * A batch of HOST image pairs (identical width/height, global SSIM only: every ssimMap must be NULL): what a

@@ -44,8 +44,12 @@ class Params(ctypes.Structure):
 
 
 class Plan(ctypes.Structure):
-    _fields_ = [("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
-                ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32), ("waveSlots", ctypes.c_uint32), ("earlyRowSums", ctypes.c_uint32)]
+    _fields_ = [("structSize", ctypes.c_uint32), ("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
+                ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32), ("waveSlots", ctypes.c_uint32), ("earlyRowSums", ctypes.c_uint32),
+                ("cellRows", ctypes.c_uint32), ("cellsX", ctypes.c_uint32), ("cellsY", ctypes.c_uint32)]
+
+
+ABI_VERSION = 4      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
 
 
 class ThreadPool(ctypes.Structure):
@@ -71,7 +75,8 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
     "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
-    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe",
+    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version",
+    "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -131,6 +136,8 @@ def load_library(path=None):
         "rmgr_ssim_hip_comm_allreduce_sums": [vp, vp, u32],
         "rmgr_ssim_hip_comm_destroy": [vp],
         "rmgr_ssim_hip_comm_rank_count": [vp, ctypes.POINTER(i32)],
+        "rmgr_ssim_hip_enqueue_rows": [vp, PP, u32, u32, vp],
+        "rmgr_ssim_hip_reduce_cells": [vp, u32, u32, u32, vp, vp],
     }
     for name, args in sig.items():
         if path is None and os.environ.get("RMGR_SSIM_LIB") and not hasattr(lib, name):
@@ -138,6 +145,12 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i32
+    if hasattr(lib, "rmgr_ssim_hip_get_abi_version"):
+        lib.rmgr_ssim_hip_get_abi_version.argtypes = []
+        lib.rmgr_ssim_hip_get_abi_version.restype = i32
+        if path is None and not os.environ.get("RMGR_SSIM_LIB") and lib.rmgr_ssim_hip_get_abi_version() != ABI_VERSION:
+            raise ImportError("%s implements rmgr/ssim-hip.h interface version %d, this binding expects %d: rebuild with `make lib`"
+                              % (p, lib.rmgr_ssim_hip_get_abi_version(), ABI_VERSION))
     lib.rmgr_ssim_hip_describe.argtypes = [vp]
     lib.rmgr_ssim_hip_describe.restype = ctypes.c_char_p
     if hasattr(lib, "rmgr_ssim_hip_comm_describe"):
@@ -152,6 +165,7 @@ def get_plan(width, height, count=1, ctx=None):
     """Strip geometry of a launch (include/rmgr/ssim-hip.h rmgr_ssim_hip_get_plan); needs no device when ctx is None."""
     lib = load_library()
     out = Plan()
+    out.structSize = ctypes.sizeof(Plan)
     _check("rmgr_ssim_hip_get_plan", lib.rmgr_ssim_hip_get_plan(ctx.handle if ctx is not None else None, width, height, count, ctypes.byref(out)))
     return out
 
@@ -359,6 +373,13 @@ class Context(object):
 
     def enqueue_batch(self, params_array, count, sums_dev_ptr):
         _check("rmgr_ssim_hip_enqueue_batch", self.lib.rmgr_ssim_hip_enqueue_batch(self.handle, count, params_array, sums_dev_ptr))
+
+    def enqueue_rows(self, params, y_begin, y_rows, cells_dev_ptr):
+        """Rows [y_begin, y_begin + y_rows) of one device-resident pair: map rows + cell partials into a zeroed cell array."""
+        _check("rmgr_ssim_hip_enqueue_rows", self.lib.rmgr_ssim_hip_enqueue_rows(self.handle, ctypes.byref(params), y_begin, y_rows, cells_dev_ptr))
+
+    def reduce_cells(self, width, height, count, cells_dev_ptr, sums_dev_ptr):
+        _check("rmgr_ssim_hip_reduce_cells", self.lib.rmgr_ssim_hip_reduce_cells(self.handle, width, height, count, cells_dev_ptr, sums_dev_ptr))
 
     # ---- native RCCL exchange (rmgr_ssim_hip_comm_*) ----
     @staticmethod

@@ -248,8 +248,9 @@ int upload_descs(rmgr_ssim_hip_Context* c, const PairDesc* descs, uint32_t count
 
 // Enqueue kernel + reduction for `count` pairs whose descriptors are in `descs` (host).
 // y_begin / y_rows / reduce: the row window of this launch (ssim_kernels.h plan()); the default is the whole image.
+// cells_out (row-band entry point only): the strips write their cell partials there instead of into the context's scratch.
 int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev,
-            uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu, bool reduce = true)
+            uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu, bool reduce = true, double* cells_out = NULL)
 {
     int variant = c->variant;
     if (variant == 0 && c->strip_rows == 0) variant = ssim_hip::default_variant(width, height, count, c->mode, c->cu_count);
@@ -262,7 +263,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     geo.map_unit = any_map && (width & 1u) == 0;     // the 8-byte map stores of the two-column kernel (ssim_kernels.hip, MAP == 2)
     for (uint32_t i = 0; i < count && geo.map_unit; ++i)
         geo.map_unit = descs[i].map != NULL && descs[i].map_step == 1;
-    int rc = grow_device(c->partials, c->partials_cap, ssim_hip::partials_size(geo));
+    int rc = cells_out ? 0 : grow_device(c->partials, c->partials_cap, ssim_hip::partials_size(geo));
     if (rc) return rc;
     PairDesc single = descs[0];
     const PairDesc* descs_dev = NULL;
@@ -275,7 +276,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     const bool launches_kernel = count > 0 && geo.strips_x > 0 && geo.strips_y > 0;
     hipEvent_t eb = NULL, ee = NULL;
     if (launches_kernel && (rc = acquire_events(c, eb, ee))) return rc;
-    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, c->partials, sums_dev, c->stream, eb, ee, reduce);
+    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, cells_out ? cells_out : c->partials, sums_dev, c->stream, eb, ee, reduce);
     if (err != hipSuccess) {
         (void)hipGetLastError();
         release_events(c, eb, ee);
@@ -658,20 +659,32 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t str
     return 0;
 }
 
+rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT
+{
+    return RMGR_SSIM_HIP_ABI_VERSION;
+}
+
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT
 {
-    if (!plan) return EINVAL;
+    if (!plan || plan->structSize < RMGR_SSIM_HIP_PLAN_MIN_SIZE) return EINVAL;
     const int mode = c ? c->mode : RMGR_SSIM_HIP_MODE_EXACT, cus = c ? c->cu_count : 256, rows = c ? c->strip_rows : 0;
     int variant = c ? c->variant : 0;
     if (variant == 0 && rows == 0) variant = ssim_hip::default_variant(width, height, count, mode, cus);    // as enqueue() does
     const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, mode, rows, variant, cus);
-    plan->stripWidth = geo.strip_w;
-    plan->stripRows = geo.strip_rows;
-    plan->stripsX = geo.strips_x;
-    plan->stripsY = geo.strips_y;
-    plan->wavefronts = geo.strips_x * geo.strips_y * count;
-    plan->waveSlots = geo.wave_slots;
-    plan->earlyRowSums = ssim_hip::uses_early_row_sums(geo, mode, variant) ? 1u : 0u;
+    rmgr_ssim_hip_Plan full;
+    memset(&full, 0, sizeof(full));
+    full.structSize = plan->structSize;
+    full.stripWidth = geo.strip_w;
+    full.stripRows = geo.strip_rows;
+    full.stripsX = geo.strips_x;
+    full.stripsY = geo.strips_y;
+    full.wavefronts = geo.strips_x * geo.strips_y * count;
+    full.waveSlots = geo.wave_slots;
+    full.earlyRowSums = ssim_hip::uses_early_row_sums(geo, mode, variant) ? 1u : 0u;
+    full.cellRows = geo.cell_rows;
+    full.cellsX = geo.cells_x;
+    full.cellsY = geo.cells_y;
+    memcpy(plan, &full, std::min<size_t>(plan->structSize, sizeof(full)));      // never beyond what the caller allocated
     return 0;
 }
 
@@ -700,6 +713,33 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_batch(rmgr_ssim_hip_Context* c, rmgr_uint32_t
     }
     delete[] descs;
     return rc;
+}
+
+rmgr_int32_t rmgr_ssim_hip_enqueue_rows(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params* params, rmgr_uint32_t yBegin, rmgr_uint32_t yRows, double* cellsDevice) RMGR_NOEXCEPT
+{
+    if (!c || !params || !cellsDevice) return EINVAL;
+    if (params->imgA.topLeft == NULL || params->imgB.topLeft == NULL) return EINVAL;
+    const uint32_t W = params->width, H = params->height, cell = ssim_hip::cell_rows_for(H);
+    if (yBegin > H || (yBegin % cell) != 0) return EINVAL;                        // bands start on reduction-cell boundaries ...
+    const uint32_t yEnd = yRows >= H - yBegin ? H : yBegin + yRows;
+    if (yEnd != H && (yEnd % cell) != 0) return EINVAL;                           // ... and end on one, or at the image's last row
+    if (W == 0 || yEnd == yBegin) return 0;
+    USE_DEVICE(c);
+    const PairDesc d = make_desc(*params);
+    return enqueue(c, W, H, 1, &d, d.map != NULL, NULL, yBegin, yEnd - yBegin, false, cellsDevice);
+}
+
+rmgr_int32_t rmgr_ssim_hip_reduce_cells(rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count,
+                                        const double* cellsDevice, double* sumsDevice) RMGR_NOEXCEPT
+{
+    if (!c || (count && (!cellsDevice || !sumsDevice))) return EINVAL;
+    if (count == 0) return 0;
+    USE_DEVICE(c);
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count);
+    int rc = grow_device(c->partials, c->partials_cap, ssim_hip::reduce_scratch_size(geo) + 1);     // the chunk sums of very large images
+    if (rc) return rc;
+    HIP_TRY(ssim_hip::launch_reduce(geo, cellsDevice, c->partials, sumsDevice, c->stream));
+    return 0;
 }
 
 rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* c, rmgr_uint32_t count, const rmgr_ssim_Params* params, float* ssim) RMGR_NOEXCEPT

@@ -122,6 +122,13 @@ size_t partials_size(const Geometry& geo);
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true);
 
+// The reduction alone: per-image sums of `geo.count` images' cell partials (partials: [image][cell_y][cell_x], the layout
+// launch() writes), in the fixed order every launch uses.  chunk_sums: reduce_scratch_size(geo) doubles of device scratch
+// (0 for images of up to 8192 cells).  For hosts that assemble an image's cells from several row-band launches -- possibly
+// on several GPUs -- before reducing them.
+size_t reduce_scratch_size(const Geometry& geo);
+hipError_t launch_reduce(const Geometry& geo, const double* partials, double* chunk_sums, double* sums, hipStream_t stream);
+
 // BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.
 hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,
                             uint32_t width, uint32_t height, hipStream_t stream);

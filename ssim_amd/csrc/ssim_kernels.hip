@@ -1416,14 +1416,19 @@ size_t partials_size(const Geometry& geo)
     return (size_t)geo.count * (per + chunks) + 1;
 }
 
-hipError_t launch_reduce(const Geometry& geo, double* partials, double* sums, hipStream_t stream)
+size_t reduce_scratch_size(const Geometry& geo)
+{
+    const size_t per = geo.partials_per_image();
+    return per > kReduceChunk ? (size_t)geo.count * ((per + kReduceChunk - 1) / kReduceChunk) : 0;
+}
+
+hipError_t launch_reduce(const Geometry& geo, const double* partials, double* chunk_sums, double* sums, hipStream_t stream)
 {
     if (geo.count == 0) return hipSuccess;
     const uint32_t per = geo.partials_per_image();
     if (per == 0) return hipMemsetAsync(sums, 0, sizeof(double) * geo.count, stream);
     if (per > kReduceChunk) {
         const uint32_t chunks = (per + kReduceChunk - 1) / kReduceChunk;
-        double* chunk_sums = partials + (size_t)geo.count * per;
         hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, chunks), dim3(kReduceThreads), 0, stream, partials, per, kReduceChunk, chunk_sums);
         hipLaunchKernelGGL(ssim_reduce_kernel, dim3(geo.count, 1), dim3(kReduceThreads), 0, stream, chunk_sums, chunks, chunks, sums);
     } else {
@@ -1466,7 +1471,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     }
     bool map = single.map != nullptr;   // for batches the ABI guarantees all-or-none and mirrors it into `single`
     if (geo.strips_x == 0 || geo.strips_y == 0)
-        return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
+        return reduce ? launch_reduce(geo, partials, partials + (size_t)geo.count * geo.partials_per_image(), sums, stream) : hipSuccess;
     if (ev_begin) { hipError_t e = hipEventRecord(ev_begin, stream); if (e != hipSuccess) return e; }
     hipError_t err;
     // variant 0: two columns per lane (ssim_strip2_kernel); 1: one column per lane (ssim_strip1_kernel); tuning: 2 forces the
@@ -1483,7 +1488,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     }
     if (err != hipSuccess) return err;
     if (ev_end) { hipError_t e = hipEventRecord(ev_end, stream); if (e != hipSuccess) return e; }
-    return reduce ? launch_reduce(geo, partials, sums, stream) : hipSuccess;
+    return reduce ? launch_reduce(geo, partials, partials + (size_t)geo.count * geo.partials_per_image(), sums, stream) : hipSuccess;
 }
 
 } // namespace ssim_hip

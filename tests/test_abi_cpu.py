@@ -276,6 +276,19 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert ssim_amd.get_plan(0, 0, 1).wavefronts == 0
     lib = ssim_amd.load_library()
     assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL
+    # the struct carries its size: a client compiled against a SHORTER Plan gets its fields and not a byte more
+    assert lib.rmgr_ssim_hip_get_abi_version() == ssim_amd.ABI_VERSION == 4
+    buf = (ctypes.c_uint32 * 16)(*([0xDEADBEEF] * 16))
+    buf[0] = 24                                                         # RMGR_SSIM_HIP_PLAN_MIN_SIZE: structSize .. wavefronts
+    assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0
+    assert list(buf[:6]) == [24, 128, 64, 32, 64, 2048] and all(v == 0xDEADBEEF for v in buf[6:])
+    buf[0] = 20
+    assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == errno.EINVAL
+    buf[0] = 64                                                         # a client from the future: only what this library knows is written
+    assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0
+    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and all(v == 0xDEADBEEF for v in buf[11:])
+    p = ssim_amd.get_plan(1920, 1080, 1)
+    assert (p.cellRows, p.cellsX, p.cellsY) == (8, 30, 135)
 
 
 def test_kernels_keep_two_waves_per_simd_and_never_spill():

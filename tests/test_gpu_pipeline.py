@@ -185,6 +185,78 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
             d.free()
 
 
+@pytest.mark.parametrize("size", [(1500, 1090), (2100, 2300), (4096, 4100)], ids=["8-row-cells", "32-row-cells", "two-reduce-chunks"])
+def test_row_bands_on_separate_contexts_equal_one_launch(gpu_ctx, size):
+    """SURVEY.md 8(e), "single huge image across GPUs": one pair cut into row bands (rmgr_ssim_hip_enqueue_rows), every band
+    computed by its OWN context -- as another GPU would -- from a buffer that holds nothing but the band's rows and 5 halo rows
+    each side, into its own zeroed cell array; the arrays added element-wise (what the all-reduce does: every cell is non-zero
+    on one rank only) and reduced (rmgr_ssim_hip_reduce_cells) must give the bits of the single launch over the whole image,
+    and the bands' map rows the same map.  Hostile values (fp64 sums inexact), three arithmetic modes, 2 / 3 / 5 bands."""
+    w, h = size
+    rng = np.random.default_rng(w * 31 + h)
+    a, b = hostile_pairs(rng, w, h, 3)[2]
+    for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_SEPARABLE, ssim_amd.MODE_DOUBLE):
+        gpu_ctx.set_mode(mode)
+        keep = []
+        try:
+            da, db, dm, ds = gpu_ctx.upload(a), gpu_ctx.upload(b), gpu_ctx.alloc(4 * w * h), gpu_ctx.alloc(8)
+            keep += [da, db, dm, ds]
+            p = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr, 1, w)
+            one = (ssim_amd.Params * 1)(p)
+            gpu_ctx.enqueue_batch(one, 1, ds.ptr)
+            gpu_ctx.synchronize()
+            want_sum = ds.download(np.float64, (1,))
+            want_map = dm.download(np.float32, (h, w))
+            plan = ssim_amd.get_plan(w, h, 1, gpu_ctx)
+            cr, ncell = plan.cellRows, plan.cellsX * plan.cellsY
+            assert cr == (32 if h >= 2048 else 8) and plan.cellsX == (w + 63) // 64 and plan.cellsY == (h + cr - 1) // cr
+            for world in (2, 3, 5):
+                cuts = [min(h, cr * ((plan.cellsY * r + world - 1) // world)) for r in range(world)] + [h]
+                total = np.zeros(ncell, np.float64)
+                band_map = gpu_ctx.alloc(4 * w * h)
+                keep.append(band_map)
+                for r in range(world):
+                    y0, y1 = cuts[r], cuts[r + 1]
+                    lo, hi = max(0, y0 - 5), min(h, y1 + 5)                  # the source rows this band may read
+                    rank = ssim_amd.Context(0, mode=mode)                   # a context of its own: nothing shared with the other bands
+                    try:
+                        ra, rb = rank.upload(a[lo:hi]), rank.upload(b[lo:hi])
+                        cells = rank.alloc(8 * ncell).upload(np.zeros(ncell, np.float64))
+                        rp = ssim_amd.make_params(w, h, ra.ptr - lo * w, 1, w, rb.ptr - lo * w, 1, w, band_map.ptr, 1, w)
+                        rank.enqueue_rows(rp, y0, y1 - y0, cells.ptr)
+                        rank.synchronize()
+                        part = cells.download(np.float64, (ncell,))
+                        first, last = (y0 // cr) * plan.cellsX, ((y1 + cr - 1) // cr) * plan.cellsX
+                        assert not part[:first].any() and not part[last:].any(), "band %d of %d wrote cells outside its rows" % (r, world)
+                        total += part                                       # adding zeros: exact
+                        for d in (ra, rb, cells):
+                            d.free()
+                    finally:
+                        rank.close()
+                dc = gpu_ctx.upload(total)
+                keep.append(dc)
+                gpu_ctx.reduce_cells(w, h, 1, dc.ptr, ds.ptr)
+                gpu_ctx.synchronize()
+                got = ds.download(np.float64, (1,))
+                assert np.array_equal(bits64(got), bits64(want_sum)), (mode, world, got, want_sum)
+                assert np.array_equal(band_map.download(np.float32, (h, w)).view(np.uint32), want_map.view(np.uint32)), (mode, world)
+            # bands start and end on cell boundaries (or at the last row)
+            lib = ssim_amd.load_library()
+            cells = gpu_ctx.alloc(8 * ncell)
+            keep.append(cells)
+            import errno
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), cr + 1, cr, cells.ptr) == errno.EINVAL
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), cr, cr + 3, cells.ptr) == errno.EINVAL
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), h + cr, cr, cells.ptr) == errno.EINVAL
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), cr, 0xFFFFFFFF, cells.ptr) == 0      # "to the end"
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), 0, cr, None) == errno.EINVAL
+            gpu_ctx.synchronize()
+        finally:
+            gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+            for d in keep:
+                d.free()
+
+
 def test_different_batches_back_to_back(gpu_ctx, oracle):
     """Six different batches (more than the descriptor ring holds) enqueued without any synchronisation in between,
     then two of them alternating: every result must be the one of its own batch."""
