@@ -65,6 +65,7 @@ HBM_PEAK_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH
 # sums, 10 packed fold adds, 14 of staging / in-range division / map value; every non-packed instruction
 # occupies one fp64-rate slot, which is what the 39.3 T/s peak counts (round 2 counted the 88 blur operations only)
 VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 137, 3: 278, 4: 119}
+FP64_MATH_OPS_PER_PIXEL = 88          # mode 2 only: the fp64 multiply-adds of blur + formula among those 137 slots (round 2's accounting; kept so that rounds compare)
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
@@ -254,10 +255,15 @@ def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
     ops = VALU_OPS_PER_PIXEL[mode]
     peak = VALU_PEAK_F64_TOPS if mode == 2 else VALU_PEAK_TOPS
     t = ops * px / sec / 1e12
+    valu = {"achieved": round(t, 2), "peak": peak, "unit": "T fp64-rate issue slots/s" if mode == 2 else "T lane-ops/s",
+            "frac": round(t / peak, 4), "ops_per_pixel": ops}
+    if mode == 2:     # both accountings: issue slots of every kind against the fp64-rate issue peak, and fp64 arithmetic alone
+        tm = FP64_MATH_OPS_PER_PIXEL * px / sec / 1e12
+        valu.update({"fp64_math_ops_per_pixel": FP64_MATH_OPS_PER_PIXEL, "fp64_math_achieved": round(tm, 2), "fp64_math_frac": round(tm / peak, 4),
+                     "note": "frac counts all 137 VALU issue slots per pixel (conversions, staging, division included; not all are fp64 arithmetic); "
+                             "fp64_math_frac counts the 88 fp64 multiply-adds only -- the figure comparable with round 2"})
     return ({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-             "algorithmic_bytes_per_launch": px * bpp},
-            {"achieved": round(t, 2), "peak": peak, "unit": "T fp64-rate issue slots/s" if mode == 2 else "T lane-ops/s",
-             "frac": round(t / peak, 4), "ops_per_pixel": ops})
+             "algorithmic_bytes_per_launch": px * bpp}, valu)
 
 
 class Batch(object):

@@ -112,7 +112,8 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint3
  * device 0 (or $RMGR_SSIM_HIP_DEVICE) is used under a lock.
  * A large pair with a map is processed in row bands -- copy-in of band k+1, kernel on band k and the copy-back of
  * band k-1's map rows (by a short-lived helper thread, straight into ssimMap) overlap; the results are bit-identical
- * to the one-launch computation.  $RMGR_SSIM_HIP_BANDS overrides the band count (1: no overlap).
+ * to the one-launch computation.  $RMGR_SSIM_HIP_BANDS overrides the band count (1: no overlap) and sends a large pair through
+ * the banded path whatever its size and whether or not a map is wanted (measurement aid).
  * The calling thread's current HIP device is left as it was (true of every function in this header).
  */
 rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* ctx, float* ssim, const rmgr_ssim_Params* params,

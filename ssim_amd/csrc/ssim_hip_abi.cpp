@@ -388,9 +388,10 @@ void rows_extent(const rmgr_ssim_ImgParams& im, uint32_t w, uint32_t r0, uint32_
 // The banded pipeline of one large host pair (see the call site), with or without a map.  `dev`/`d` address the staged
 // device copies (not yet filled), loA/loB are the byte offsets of the images' lowest addresses relative to topLeft.
 // Without a map there is nothing to send back and no helper thread: the bands only hide the kernel behind the H2D copy
-// of the following band.  Measured (round 3, profiles/r03_host_probe.txt): every additional pageable copy costs ~20 us,
-// more than the ~12 us of kernel a band hides at 4096^2 (0.742 ms unbanded, 0.762 / 0.790 / 0.891 ms at 2 / 4 / 8 bands);
-// it pays from 8192^2 on (2.795 -> 2.650 ms at 4 bands), so only such images take this path without a map.
+// of the following band.  Measured (round 3, profiles/r03_host_probe.txt, on a build that banded every map-less call): every
+// additional pageable copy costs ~20 us, more than the ~12 us of kernel a band hides at 4096^2 (0.742 ms unbanded, 0.762 /
+// 0.790 / 0.891 ms at 2 / 4 / 8 bands); it pays from 8192^2 on (2.795 -> 2.650 ms at 4 bands), so by default only such images
+// take this path without a map ($RMGR_SSIM_HIP_BANDS forces it for any size: tools/host_call_probe.py).
 int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rmgr_ssim_Params& dev, const PairDesc& d, int64_t loA, int64_t loB)
 {
     (void)dev;
@@ -940,7 +941,9 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     // bit-identical to the one-launch result) and band k-1's map rows travel back, written by a helper thread
     // straight into the caller's buffer.
     // Without a map a few bands hide the kernel behind the copy, which pays only for very large images (compute_banded()).
-    if (!staged && bandable(*params) && (params->ssimMap || (uint64_t)W * H >= (uint64_t(1) << 26))) {
+    // An explicit $RMGR_SSIM_HIP_BANDS always takes the banded path (so that a band sweep measures what it says it does).
+    const bool bands_forced = getenv("RMGR_SSIM_HIP_BANDS") != NULL;
+    if (!staged && bandable(*params) && (params->ssimMap || bands_forced || (uint64_t)W * H >= (uint64_t(1) << 26))) {
         if ((rc = compute_banded(c, *params, dev, d, loA, loB))) return rc;
     } else {
         if (!staged) {

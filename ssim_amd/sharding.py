@@ -34,6 +34,15 @@ def split_batch(total_pairs, world):
     return out
 
 
+def split_rows(height, cell_rows, world):
+    """Row bands of ONE image for `world` ranks (rmgr_ssim_hip_enqueue_rows): contiguous [y0, y1) ranges that start on
+    reduction-cell boundaries (cell_rows = 8, or 32 for images of >= 2048 rows: rmgr_ssim_hip_get_plan) and split the
+    image's cell rows as evenly as they go; ranks beyond the number of cell rows get an empty band."""
+    cells_y = (height + cell_rows - 1) // cell_rows
+    cuts = [min(height, cell_rows * ((cells_y * r + world - 1) // world)) for r in range(world)] + [height]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def exchange_sums(sums_all, work, dist):
     """sums_all: float64 tensor [total pairs], zero outside this rank's slice.  Returns the tensor
     holding every rank's sums (work, all-reduced) -- or sums_all itself for a single process."""

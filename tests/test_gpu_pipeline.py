@@ -211,12 +211,13 @@ def test_row_bands_on_separate_contexts_equal_one_launch(gpu_ctx, size):
             cr, ncell = plan.cellRows, plan.cellsX * plan.cellsY
             assert cr == (32 if h >= 2048 else 8) and plan.cellsX == (w + 63) // 64 and plan.cellsY == (h + cr - 1) // cr
             for world in (2, 3, 5):
-                cuts = [min(h, cr * ((plan.cellsY * r + world - 1) // world)) for r in range(world)] + [h]
+                from ssim_amd import sharding
+                bands = sharding.split_rows(h, cr, world)
                 total = np.zeros(ncell, np.float64)
                 band_map = gpu_ctx.alloc(4 * w * h)
                 keep.append(band_map)
                 for r in range(world):
-                    y0, y1 = cuts[r], cuts[r + 1]
+                    y0, y1 = bands[r]
                     lo, hi = max(0, y0 - 5), min(h, y1 + 5)                  # the source rows this band may read
                     rank = ssim_amd.Context(0, mode=mode)                   # a context of its own: nothing shared with the other bands
                     try:

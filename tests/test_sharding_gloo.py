@@ -186,6 +186,14 @@ def test_shard_helpers():
     assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
     with pytest.raises(ValueError):
         sharding.shard_range(2, 2, 1)
+    # row bands of one image: cell-aligned, contiguous, covering, as even as the cell rows allow
+    assert sharding.split_rows(8192, 32, 8) == [(1024 * r, 1024 * (r + 1)) for r in range(8)]
+    assert sharding.split_rows(1080, 8, 4) == [(0, 272), (272, 544), (544, 816), (816, 1080)]
+    assert sharding.split_rows(20, 8, 5) == [(0, 8), (8, 16), (16, 16), (16, 20), (20, 20)]       # more ranks than cell rows: some bands are empty
+    for h, cr, n in ((4100, 32, 3), (77, 8, 2), (1, 8, 4)):
+        bands = sharding.split_rows(h, cr, n)
+        assert bands[0][0] == 0 and bands[-1][1] == h and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+        assert all(y0 % cr == 0 for y0, _ in bands if y0 < h)
 
 
 def test_synthetic_generators_agree():

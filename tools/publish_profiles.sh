@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/.."
 P=$1
-R=${2:-r03}
+R=${2:-r04}
 note="-- PMC passes (one rocprofv3 run per counter set). FETCH_SIZE is KiB and reads 1/2 of the true bytes (profiles/r01_fetch_size_calibration.md)"
 pmc() { python3 tools/summarize_prof.py "round ${R#r0}, final kernel: tools/profile_target.py $2 $note" $P/$1_fetch/t_kernel_trace.csv $P/$1_fetch/t_counter_collection.csv $P/$1_write/t_counter_collection.csv $P/$1_sq/t_counter_collection.csv $P/$1_sq2/t_counter_collection.csv > profiles/$3; }
 pmc 4k     "8 x 4096^2 (no map), MODE_EXACT"        ${R}_final_exact_4k_pmc.md
@@ -21,7 +21,7 @@ cp $P/trace/t_kernel_stats.csv profiles/${R}_final_bench_kernel_stats.csv
 python3 tools/summarize_prof.py "round ${R#r0}, final kernel: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (32 x 4096^2 per step; 20 timed steps + gate, clock-settle and warm-up launches; also the fast-mode and single-pair legs)" $P/trace/t_kernel_trace.csv > profiles/${R}_final_bench_kernel_trace.md
 cp $P/mode_speeds.txt profiles/${R}_final_mode_speeds.txt
 cp $P/error_table.md profiles/${R}_error_table.md
-for f in bench_rccl_1rank.json bench_c4_strong.json host_call_probe.txt latency_probe.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_final_$f; done
+for f in bench_rccl_1rank.json bench_rccl_1rank_torch.json bench_c4_strong.json host_call_probe.txt latency_probe.txt rccl_selftest.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_final_$f; done
 python3 - "$P" "$R" <<'PY'
 import csv, json, sys
 P, R = sys.argv[1], sys.argv[2]
