@@ -225,10 +225,16 @@ rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uin
  * arrives is reported here as ETIMEDOUT after $RMGR_SSIM_HIP_COMM_TIMEOUT_S seconds (default 30): get_unique_id and
  * comm_init (library load, bootstrap, rendezvous), the enqueue inside comm_allreduce_sums, rmgr_ssim_hip_synchronize()
  * on a context that owns a communicator (the queued collective's peers may never launch theirs), and comm_destroy all
- * return by that deadline.  After ETIMEDOUT from anything but get_unique_id the communicator has been aborted
- * (ncclCommAbort) and the context is back in its single-GPU state; comm_init may be called again.  The communicator is
- * created non-blocking (ncclCommInitRankConfig) when the loaded RCCL offers it; $RMGR_SSIM_HIP_COMM_BLOCKING=1 asks for a
- * blocking one (its init is still bounded, by a helper thread that is abandoned when it does not return).
+ * return by that deadline.  After ETIMEDOUT the context is back in its single-GPU state -- it still computes, and
+ * comm_init may be called again (tests/test_gpu_zz_rccl.py does both).  How: library load, ncclGetUniqueId and the
+ * communicator's creation run on a helper thread the caller waits for with a timeout; the communicator is requested
+ * non-blocking (ncclCommInitRankConfig, blocking = 0) and, if the deadline passes while its rendezvous is in progress,
+ * aborted (ncclCommAbort) by the helper.  On the RCCL builds of this image (2.26.6 in the PyTorch wheel, 2.27.7 in
+ * /opt/rocm) that call carries the rendezvous out before it returns, blocking = 0 notwithstanding (measured:
+ * profiles/r04_final_rccl_selftest.txt), so what bounds comm_init there is the helper's timeout: the helper stays parked
+ * inside RCCL and is abandoned (one idle thread; nothing it touches lives on the caller's stack).
+ * $RMGR_SSIM_HIP_COMM_BLOCKING=1 asks for a plain blocking communicator; $RMGR_SSIM_HIP_COMM_DEBUG=1 logs the helper's
+ * steps on stderr.
  */
 #define RMGR_SSIM_HIP_COMM_ID_BYTES 128
 rmgr_int32_t rmgr_ssim_hip_comm_get_unique_id(unsigned char id[RMGR_SSIM_HIP_COMM_ID_BYTES]) RMGR_NOEXCEPT;

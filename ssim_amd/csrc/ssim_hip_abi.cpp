@@ -1181,11 +1181,12 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_compute_ssim_luminance_host(rmgr_ssim_hip_
 // 30 s): loading the library, the bootstrap behind ncclGetUniqueId, the rendezvous of ncclCommInitRank, the enqueue of the
 // all-reduce, the teardown.  The reference turns a failed worker into a bounded ECHILD return (src/ssim.cpp:1094-1097);
 // the GPU-era counterpart of "a worker failed" is "a rank never arrived", and that must come back as an errno
-// (ETIMEDOUT) too, not as a hang.  Mechanics: the communicator is created NON-BLOCKING (ncclCommInitRankConfig,
-// blocking = 0), its state polled with ncclCommGetAsyncError and, past the deadline, torn down with ncclCommAbort; and
-// the calls that have no asynchronous form (dlopen, ncclGetUniqueId, ncclCommInitRank on an RCCL without the config entry
-// point) run on a helper thread the caller waits for with a timeout -- a helper that never returns is abandoned (the
-// process keeps one parked thread; nothing it owns lives on the caller's stack).
+// (ETIMEDOUT) too, not as a hang.  Mechanics: library load, ncclGetUniqueId and the communicator's creation run on a helper
+// thread the caller waits for with a timeout; the communicator is requested NON-BLOCKING (ncclCommInitRankConfig, blocking
+// = 0), its state polled with ncclCommGetAsyncError and, past the deadline, torn down with ncclCommAbort by the helper.  The
+// RCCL builds of this image (2.26.6, 2.27.7) run the rendezvous inside ncclCommInitRankConfig all the same (the helper's log
+// shows the call returning only when the communicator is ready), so there the helper's timeout is the bound that acts: a
+// helper that never returns is abandoned -- the process keeps one parked thread; nothing it owns lives on the caller's stack.
 namespace {
 
 struct Rccl {
