@@ -1310,15 +1310,16 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
     else if (j->want_id) { rc = map_nccl(r->GetUniqueId(&j->id)); comm_debug("helper: ncclGetUniqueId returned", seconds_since(t0)); }
     else if (hipSetDevice(j->device) != hipSuccess) { (void)hipGetLastError(); rc = ENODEV; }
     else {
-        ncclResult_t res = ncclInvalidUsage;
-        bool tried_config = false;
+        ncclResult_t res;
         if (j->nonblocking_ok && r->CommInitRankConfig && r->CommGetAsyncError && r->CommAbort) {
             ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
             cfg.blocking = 0;
             res = r->CommInitRankConfig(&j->comm, j->rank_count, j->id, j->rank, &cfg);
-            tried_config = (res == ncclSuccess || res == ncclInProgress);
-            comm_debug(tried_config ? "helper: ncclCommInitRankConfig(blocking = 0) accepted" : "helper: ncclCommInitRankConfig refused, falling back to ncclCommInitRank", seconds_since(t0));
-            if (tried_config) {
+            char msg[96];
+            snprintf(msg, sizeof(msg), "helper: ncclCommInitRankConfig(blocking = 0) returned %d", (int)res);
+            comm_debug(msg, seconds_since(t0));
+            // An error here is final (no second attempt with the plain call: the id's rendezvous has been used).
+            if (res == ncclSuccess || res == ncclInProgress) {
                 j->nonblocking = true;
                 for (;;) {                                   // the rendezvous proceeds on RCCL's own thread
                     ncclResult_t state = ncclSuccess;
@@ -1330,11 +1331,11 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
                 }
                 comm_debug(res == ncclSuccess ? "helper: communicator ready" : res == ncclInProgress ? "helper: deadline passed, aborting the communicator" : "helper: init failed, aborting the communicator", seconds_since(t0));
                 if (res != ncclSuccess && j->comm) { (void)r->CommAbort(j->comm); j->comm = NULL; comm_debug("helper: ncclCommAbort returned", seconds_since(t0)); }
-            } else {
-                j->comm = NULL;                              // a config this RCCL does not take: the plain call below
             }
+        } else {
+            res = r->CommInitRank(&j->comm, j->rank_count, j->id, j->rank);
+            comm_debug("helper: ncclCommInitRank returned", seconds_since(t0));
         }
-        if (!tried_config) { res = r->CommInitRank(&j->comm, j->rank_count, j->id, j->rank); comm_debug("helper: ncclCommInitRank returned", seconds_since(t0)); }
         if (res != ncclSuccess) j->comm = NULL;
         rc = map_nccl(res);
     }

@@ -52,6 +52,20 @@ def test_comm_init_with_an_absent_peer_times_out_instead_of_hanging():
     run_selftest("absent-peer", comm_timeout=5)
 
 
+def test_two_processes_rendezvous_through_the_native_api():
+    """Two PROCESSES -- rank 0 creates the id, rank 1 receives its 128 bytes on its command line -- join one communicator
+    through rmgr_ssim_hip_comm_init, both on device 0, the only GPU of a test box.  RCCL refuses two ranks on one device, but
+    it can only find that out after the two processes have met: bootstrap over the id, exchange of the peers' device
+    information.  So: both ranks must come back with the SAME verdict inside the deadline -- EINVAL (ncclInvalidUsage,
+    "duplicate GPU") on this RCCL, or a working 2-rank communicator whose all-reduce adds the two vectors on one that allows
+    it -- and nobody hangs.  The nearest a 1-GPU box gets to the N > 1 exchange of bench.py --exchange native."""
+    r = run_selftest("two-ranks", comm_timeout=20)
+    verdicts = [l.split("VERDICT ", 1)[1] for l in r.stderr.splitlines() if "VERDICT " in l]
+    assert len(verdicts) == 2 and verdicts[0] == verdicts[1], verdicts
+    assert verdicts[0] in ("errno 22", "2-rank communicator on one GPU works"), verdicts
+    print("two ranks on one GPU:", verdicts[0])
+
+
 def test_config4_shards_through_the_native_allreduce():
     """One rank's share of configs[3] (128 x 1080p) as 8 / 3 / 5 emulated shards + the all-reduce of the whole vector on a
     1-rank communicator == the single batch, bit for bit (the communicator-free form of this comparison, at all 1024 pairs,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Self-tests of the native RCCL exchange (rmgr_ssim_hip_comm_*) on ONE GPU, each in its own process.
 
-    python3 tools/rccl_selftest.py [single|absent-peer|shards] [--with-torch]      -> "RESULT ok" on stderr, exits 0
+    python3 tools/rccl_selftest.py [single|absent-peer|two-ranks|shards] [--with-torch]      -> "RESULT ok" on stderr, exits 0
 
 single       a 1-rank communicator leaves the per-image sums bit-identical (what N ranks add is zeros); RCCL itself counts
              one rank; a second comm_init is EINVAL; destroy, then a fresh communicator works again.
@@ -9,6 +9,9 @@ absent-peer  rank 1 of 2 whose rank 0 never shows up: comm_init must come back w
              ($RMGR_SSIM_HIP_COMM_TIMEOUT_S, set short here) instead of hanging, the context must still compute, and a
              1-rank communicator must still initialise afterwards.  The bounded-failure contract of the reference
              (a failed worker -> ECHILD, src/ssim.cpp:1094-1097) for the multi-GPU exchange.
+two-ranks    two processes (this one starts rank 1 with the id on its command line), both on device 0, join ONE communicator:
+             the real N > 1 rendezvous as far as a 1-GPU box can take it.  RCCL refuses two ranks on one device (EINVAL) --
+             after the ranks have met; both must report the same verdict inside the deadline.
 shards       one rank's share of BASELINE.json configs[3] (128 x 1080p) cut into 8 / 3 / 5 emulated shards, each enqueued
              into its slice of a zeroed vector, then rmgr_ssim_hip_comm_allreduce_sums over the whole vector on a 1-rank
              communicator == the single batch, bit for bit.
@@ -43,6 +46,8 @@ faulthandler.dump_traceback_later(LIMIT, exit=True)
 
 ARGS = [a for a in sys.argv[1:] if not a.startswith("--")]
 WHAT = ARGS[0] if ARGS else "single"
+UID_HEX = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--rank1=")] or [""])[0]
+RANK = 1 if UID_HEX else 0
 if "--with-torch" in sys.argv:
     stage("import torch (bundled HIP runtime + RCCL)")
     import torch  # noqa: F401
@@ -188,11 +193,50 @@ def shards(ctx):
     ctx.comm_destroy()
 
 
+def two_ranks(ctx):
+    """Two processes, both on device 0 (all a test box has): does this RCCL take two ranks of one communicator on ONE GPU?
+    Either answer is fine -- what is checked is that both ranks come back with the SAME verdict inside the deadline: a 2-rank
+    communicator that RCCL itself counts as 2 ranks and whose all-reduce adds the two ranks' vectors, or an errno on both."""
+    import subprocess
+    n = 8
+    mine = np.arange(1, n + 1, dtype=np.float64) * (1.0 if RANK == 0 else 0.5)
+    if RANK == 0:
+        stage("rank 0: comm_unique_id")
+        uid = ssim_amd.Context.comm_unique_id()
+        stage("rank 0: starting rank 1")
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "two-ranks", "--rank1=" + uid.hex()], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    else:
+        uid = bytes.fromhex(UID_HEX)
+    sums = ctx.alloc(8 * n).upload(mine)
+    verdict = "?"
+    try:
+        stage("rank %d: comm_init(2 ranks)" % RANK)
+        t = time.time()
+        ctx.comm_init(uid, 2, RANK)
+        stage("rank %d: comm_init done in %.2f s; RCCL counts %d rank(s)" % (RANK, time.time() - t, ctx.comm_rank_count()))
+        assert ctx.comm_rank_count() == 2
+        ctx.comm_allreduce_sums(sums.ptr, n)
+        ctx.synchronize()
+        got = sums.download(np.float64, (n,))
+        assert np.array_equal(got, np.arange(1, n + 1, dtype=np.float64) * 1.5), got
+        ctx.comm_destroy()
+        verdict = "2-rank communicator on one GPU works"
+    except ssim_amd.SsimError as e:
+        stage("rank %d: errno %d after %.2f s" % (RANK, e.errno, time.time() - t))
+        verdict = "errno %d" % e.errno
+    stage("rank %d: VERDICT %s" % (RANK, verdict))
+    if RANK == 0:
+        out, err = child.communicate(timeout=LIMIT)
+        sys.stderr.write("".join("    | " + l + "\n" for l in err.splitlines() if "rccl_selftest" in l or "rmgr-ssim comm" in l or "WARN" in l))
+        theirs = [l.split("VERDICT ", 1)[1] for l in err.splitlines() if "VERDICT " in l]
+        assert child.returncode == 0 and theirs == [verdict], (child.returncode, theirs, verdict)
+
+
 def main():
     stage("create context on device 0")
     ctx = ssim_amd.Context(0)
     stage(ctx.describe())
-    {"single": single, "absent-peer": absent_peer, "shards": shards}[WHAT](ctx)
+    {"single": single, "absent-peer": absent_peer, "shards": shards, "two-ranks": two_ranks}[WHAT](ctx)
     stage("close")
     ctx.close()
     faulthandler.cancel_dump_traceback_later()
