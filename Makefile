@@ -19,11 +19,16 @@ all: lib oracle
 
 lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim-hip-double.so $(OUT)/librmgr-ssim.a $(OUT)/librmgr-ssim-openmp.a $(BIN)/rmgr-ssim
 
-# Static flavour under the reference's archive name (CMakeLists.txt:205): the same three objects.  A program
-# that links it also needs the HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
+# Static flavour under the reference's archive name (CMakeLists.txt:205): the same three objects, linked into ONE relocatable
+# object whose only global symbols are the API (the shared libraries' export list has no counterpart for archives: the
+# internal ssim_hip:: interface between the ABI layer and the kernels would otherwise be visible to -- and collide with --
+# whatever else the program links; the reference's archive exposes its API only).  A program that links it also needs the
+# HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
 $(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
 	@mkdir -p $(OUT)
-	rm -f $@ && ar rcs $@ $^
+	ld -r -o $(OBJ)/rmgr_ssim_api.o $^
+	objcopy --wildcard --keep-global-symbol='rmgr_ssim_*' --keep-global-symbol='_ZN4rmgr4ssim12compute_ssimE*' --keep-global-symbol='_ZN4rmgr4ssim11select_implE*' $(OBJ)/rmgr_ssim_api.o
+	rm -f $@ && ar rcs $@ $(OBJ)/rmgr_ssim_api.o
 
 # The reference's second archive (CMakeLists.txt:229: rmgr-ssim-openmp = src/ssim-openmp.c).  Here the OpenMP entry
 # point is a forwarder that lives in ssim_dropin.o already; the archive exists so that a link line written for the

@@ -372,6 +372,7 @@ def main():
                     help="N > 1: who carries the all-reduce of the per-image sums.  native = the product's own rmgr_ssim_hip_comm_* (RCCL behind "
                          "the C ABI; rank 0's communicator id travels over the launcher's process group); torch = torch.distributed.all_reduce; "
                          "auto (default) = native when its communicator comes up on every rank within the deadline, else torch -- the line says which")
+    ap.add_argument("--watchdog", type=float, default=900.0, metavar="SECONDS", help="dump all Python stacks and exit non-zero if the run takes longer than this (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
     ap.add_argument("--print-launch", action="store_true", help="print the rank launcher command for --gpus N and exit (no GPU needed)")
@@ -392,6 +393,14 @@ def main():
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])
+
+    # A run that stops making progress (a collective whose peer died, a box that lost its GPU) must end with a diagnosis, not
+    # sit until somebody's outer limit kills it silently: after --watchdog seconds every thread's Python stack goes to stderr
+    # and the process exits non-zero.  (The native exchange has its own, much shorter deadlines.)
+    if args.watchdog > 0:
+        import faulthandler
+        faulthandler.enable()
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     # stdout carries exactly one line, the JSON of rank 0: native libraries write banners to file descriptor 1 (RCCL
     # prints its version block there), so everything else is sent to stderr and the line goes to the saved descriptor.

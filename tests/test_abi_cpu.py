@@ -46,6 +46,16 @@ def test_library_exports_nothing_but_the_api(name):
     assert exported == allowed, (sorted(exported - allowed), sorted(allowed - exported))
 
 
+def test_static_archive_exposes_nothing_but_the_api():
+    """The archive under the reference's name (librmgr-ssim.a): one relocatable object whose global definitions are the
+    declared API, as in the shared libraries -- a program that links it must not see (or collide with) ssim_hip::*."""
+    path = os.path.join(os.path.dirname(ssim_amd.LIB_PATH), "librmgr-ssim.a")
+    out = subprocess.run(["nm", "--defined-only", "-g", path], capture_output=True, text=True, check=True).stdout
+    exported = set(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3)
+    allowed = declared_c_functions() | set(ssim_amd.CXX_SYMBOLS)
+    assert exported == allowed, (sorted(exported - allowed), sorted(allowed - exported))
+
+
 def test_struct_layouts_match_reference_abi():
     # LP64 layout of include/rmgr/ssim.h:469-533 of the reference
     assert ctypes.sizeof(ssim_amd.Version) == 24
