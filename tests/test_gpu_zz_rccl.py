@@ -20,18 +20,18 @@ pytestmark = [pytest.mark.gpu, pytest.mark.rccl]
 TOOL = os.path.join(ROOT, "tools", "rccl_selftest.py")
 
 
-def run_selftest(*args, limit=50, comm_timeout=None):
+def run_selftest(*args, limit=50, comm_timeout=None, extra=0):
     env = dict(os.environ, NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,BOOTSTRAP,NET", HSA_ENABLE_IPC_MODE_LEGACY="0",
                RCCL_SELFTEST_LIMIT_S=str(limit))
     if comm_timeout is not None:
         env["RMGR_SSIM_HIP_COMM_TIMEOUT_S"] = str(comm_timeout)
     try:
-        r = subprocess.run([sys.executable, TOOL] + list(args), capture_output=True, text=True, timeout=limit + 10, env=env)
+        r = subprocess.run([sys.executable, TOOL] + list(args), capture_output=True, text=True, timeout=limit + extra + 10, env=env)
     except subprocess.TimeoutExpired as e:       # the child's own watchdog did not fire: subprocess.run() has killed it
         out = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
         err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
         pytest.fail("rccl_selftest %s did not finish in %d s and was killed.\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
-                    % (" ".join(args), limit + 10, out[-1500:], err[-6000:]))
+                    % (" ".join(args), limit + extra + 10, out[-1500:], err[-6000:]))
     assert r.returncode == 0 and "RESULT ok" in r.stderr, (
         "rccl_selftest %s failed (exit %d).\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
         % (" ".join(args), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
@@ -76,4 +76,4 @@ def test_config4_shards_through_the_native_allreduce():
 def test_native_rccl_exchange_inside_a_torch_process():
     """The same 1-rank exchange in a process that imported torch first: the library must pick up the RCCL (and HIP runtime)
     already in the process -- torch's bundled copies -- which is the configuration of `bench.py --exchange native`."""
-    run_selftest("single", "--with-torch", limit=110)
+    run_selftest("single", "--with-torch", extra=300)      # + the child's own limit for a first `import torch` on a fresh box

@@ -49,9 +49,15 @@ WHAT = ARGS[0] if ARGS else "single"
 UID_HEX = ([a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--rank1=")] or [""])[0]
 RANK = 1 if UID_HEX else 0
 if "--with-torch" in sys.argv:
+    # the first import of torch on a fresh box pages in gigabytes (1-2 minutes have been seen): that is the image, not
+    # RCCL, so it gets its own generous limit and the RCCL part's watchdog is armed afterwards
+    faulthandler.cancel_dump_traceback_later()
+    faulthandler.dump_traceback_later(float(os.environ.get("RCCL_SELFTEST_TORCH_IMPORT_LIMIT_S", "300")), exit=True)
     stage("import torch (bundled HIP runtime + RCCL)")
     import torch  # noqa: F401
     stage("torch %s imported" % torch.__version__)
+    faulthandler.cancel_dump_traceback_later()
+    faulthandler.dump_traceback_later(LIMIT, exit=True)
 
 import numpy as np  # noqa: E402
 
@@ -138,8 +144,11 @@ def absent_peer(ctx):
     ctx.synchronize()
     before = sums.download(np.float64, (n,))
     limit = float(os.environ["RMGR_SSIM_HIP_COMM_TIMEOUT_S"])
+    # the short deadline is for the call under test only: the first load of the 573 MB library on a cold box alone can take 5 s
+    os.environ["RMGR_SSIM_HIP_COMM_TIMEOUT_S"] = "30"
     stage("comm_unique_id")
     uid = ssim_amd.Context.comm_unique_id()
+    os.environ["RMGR_SSIM_HIP_COMM_TIMEOUT_S"] = str(limit)
     stage("comm_init as rank 1 of 2 -- rank 0 never arrives; deadline %.0f s" % limit)
     t = time.time()
     try:
@@ -150,6 +159,7 @@ def absent_peer(ctx):
         stage("comm_init -> errno %d after %.2f s" % (e.errno, dt))
         assert e.errno == ETIMEDOUT, e
         assert limit - 0.5 <= dt <= limit + 2.0, dt          # AT the deadline: the abort of the half-built communicator runs in the background
+    os.environ["RMGR_SSIM_HIP_COMM_TIMEOUT_S"] = "30"
     assert ctx.comm_rank_count() == 0
     stage("the context still computes")
     ctx.enqueue_batch(params, n, sums.ptr)
