@@ -360,8 +360,8 @@ def shard_table(args, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: ~0.5 s of GPU time on the default workload, long enough for an outside utilisation sampler to see it)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="4k")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU per step (weak) / in total (strong); 0: the workload's default")
@@ -575,7 +575,7 @@ def main():
                 ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
             ctx.synchronize()
             ctx.set_profiling(True)
-            for _ in range(max(args.steps // 2, 3)):
+            for _ in range(min(max(args.steps // 2, 3), 100)):
                 ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
             ctx.synchronize()
             n_f, ms_f = ctx.get_profile()
@@ -650,7 +650,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs and args.mode == 0 and args.variant == 0 and args.strip_rows == 0:
         del batch                                  # free the headline batch first
         torch.cuda.empty_cache()
-        ksteps = max(args.steps // 2, 5)
+        ksteps = min(max(args.steps // 2, 5), 100)
         w8, h8 = 8192, 8192
         configs["8k-map exact"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "8k-map exact", w8, h8, 2, True, 0, WORKLOADS["8k-map"][5], ksteps)
         configs["8k-map fast"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "8k-map fast", w8, h8, 2, True, 1, WORKLOADS["8k-map"][5], ksteps)
