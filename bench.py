@@ -68,8 +68,9 @@ VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 137, 3: 278, 4: 119}
 FP64_MATH_OPS_PER_PIXEL = 88          # mode 2 only: the fp64 multiply-adds of blur + formula among those 137 slots (round 2's accounting; kept so that rounds compare)
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
-VALU_MEASURED_PEAK_TOPS = 68.7        # best v_pk_fma_f32 rate tools/valu_probe.hip reaches on this chip: 8 waves/SIMD (profiles/r01_valu_probe.txt)
-VALU_MEASURED_2WAVE_TOPS = 58.1       # the same probe at the 2 waves/SIMD the kernel's 110 accumulator VGPRs allow
+VALU_MEASURED_PEAK_TOPS = 74.6        # best v_pk_fma_f32 rate this chip sustains: 8 waves/SIMD, tools/occupancy_probe.hip (profiles/r04_occupancy_probe.txt)
+VALU_MEASURED_2WAVE_TOPS = 65.1       # the same stream with the occupancy FORCED to the 2 waves/SIMD the kernel's 110 accumulator VGPRs allow (rounds
+                                      # 1-3 quoted 58.1 / 68.7 from tools/valu_probe.hip, whose launches did not force an even placement of the waves)
 MODE_NAMES = ["exact (reference FMA order, bit-faithful)", "fast (reference-order E planes + separable mu planes; inside the FMA-relative tolerance)",
               "double (fp64 internals)", "unfused (reference AVX order)", "separable (all planes separable fp32, four planes, centred; reference test tolerance vs the exact value)"]
 # tests/ssim_naive.h<double> known answers of the synthetic pairs, seeds 0x5EED, 0x5EEE, ...
