@@ -373,6 +373,10 @@ def main():
                     help="N > 1: who carries the all-reduce of the per-image sums.  native = the product's own rmgr_ssim_hip_comm_* (RCCL behind "
                          "the C ABI; rank 0's communicator id travels over the launcher's process group); torch = torch.distributed.all_reduce; "
                          "auto (default) = native when its communicator comes up on every rank within the deadline, else torch -- the line says which")
+    ap.add_argument("--sustain", type=float, default=6.0, metavar="SECONDS",
+                    help="after the timed region: the same step repeated for about SECONDS on every rank (the same number of steps on all of them), "
+                         "reported as `sustained` -- throughput at thermal / clock steady state, and long enough for an outside utilisation sampler "
+                         "to see the GPUs busy (0: off; never part of `value`)")
     ap.add_argument("--watchdog", type=float, default=900.0, metavar="SECONDS", help="dump all Python stacks and exit non-zero if the run takes longer than this (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
@@ -567,6 +571,29 @@ def main():
                 raise SystemExit("rank %d: the torch exchange returned different sums than the native one" % rank)
             exchange["crosscheck"] = "torch.distributed.all_reduce delivers the same vector bit for bit (untimed step)"
 
+    # --- sustained rate: the same step (kernel + exchange) for about --sustain seconds, the same number of steps on every rank
+    #     (derived from the all-reduced elapsed time, so the collectives pair up); never `value` ---
+    sustained = {}
+    if args.sustain > 0:
+        n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)))
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        fence()
+        dt_sus = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt_sus], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_sus = float(t.item())
+        sustained = {"steps": n_sus, "seconds": round(dt_sus, 3), "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                     "mpix_s": round(float(total) * W * H * n_sus / dt_sus / 1e6, 1),
+                     "vs_value": round((elapsed / args.steps) / (dt_sus / n_sus), 4),
+                     "note": "the timed step repeated back to back for ~%.0f s (max over ranks): throughput at clock / thermal steady state; not `value`" % args.sustain}
+        last = work if dist is not None else sums_all
+        if not np.array_equal(last.cpu().numpy().view(np.uint64), full_bits):
+            raise SystemExit("rank %d: the sustained steps returned different sums than the gated step" % rank)
+
     # --- the two opt-in modes on the same batch (kernel time only; never `value`) ---
     other = {}
     if args.mode == 0 and rank == 0 and mine:
@@ -694,6 +721,7 @@ def main():
             "exchange": exchange,
             "roofline": roof,
             "valu": valu,
+            "sustained": sustained,
             "single_pair": single,
             "fast_mode": other.get("fast_mode", {}),
             "separable_mode": other.get("separable_mode", {}),
