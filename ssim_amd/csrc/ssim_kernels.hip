@@ -1251,41 +1251,58 @@ hipError_t launch_strip1(const Geometry& geo, const KArgs& ka, bool map, hipStre
 namespace {
 
 // Y = (R*19595 + G*38470 + B*7471 + 32768) / 65536: the integer BT.601 weights of the reference's
-// CLI (src/ssim-cli.cpp:158-186).  HBM-bound (3-4 B read, 1 B written per pixel): packed-RGB rows whose
-// addresses allow it are read as three dwords per four pixels and written as one dword; any other
-// layout takes the per-pixel path.
+// CLI (src/ssim-cli.cpp:158-186).  A byte kernel, HBM-bound (3-4 B read, 1 B written per pixel): what matters is that a
+// wave touches memory in whole dwords.  Pixels of 3 bytes (RGB) or 4 (RGBA / RGBX) are processed FOUR per thread -- three
+// or four dwords read, one dword written -- at ANY byte alignment of the rows: global memory takes dword accesses at odd
+// addresses on gfx950 (the type below tells the compiler not to assume more), so neither an odd row pitch nor an odd base
+// address sends a frame to the per-pixel path (round 4, 8192^2: RGBA 158.8 -> 55.0 us, RGB with an odd row pitch 110.8 -> 39.7 us;
+// 16384^2, beyond the 256 MB Infinity Cache: 5.8 / 6.3 / 4.8 TB/s of algorithmic bytes for RGB / RGBA / odd-pitch RGB;
+// tools/luminance_probe.py, profiles/r04_luminance_probe.txt).
+// Any other step (planar-with-gaps layouts, negative steps) takes one pixel per thread.
 __device__ __forceinline__ uint32_t bt601(uint32_t r, uint32_t g, uint32_t b)
 {
     return (r * 19595u + g * 38470u + b * 7471u + 32768u) >> 16;
 }
 
+typedef uint32_t __attribute__((aligned(1))) u32_any;     // a dword at any byte address
+
+template <int PX>      // bytes per pixel of the four-pixels-per-thread form: 3 or 4; 0 = any step, one pixel per thread
 __global__ __launch_bounds__(256) void luminance_kernel(uint8_t* __restrict__ dst, int64_t dst_stride, const uint8_t* __restrict__ src,
-                                                       int64_t src_step, int64_t src_stride, uint32_t width, uint32_t height, int packed)
+                                                       int64_t src_step, int64_t src_stride, uint32_t width, uint32_t height)
 {
     const uint32_t y = blockIdx.y;
     const uint8_t* srow = src + (int64_t)y * src_stride;
     uint8_t* drow = dst + (int64_t)y * dst_stride;
-    const uint32_t quads = width >> 2;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (packed) {
-        if (i < quads) {
-            const uint32_t* p = reinterpret_cast<const uint32_t*>(srow) + 3 * (size_t)i;
-            const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
-            const uint32_t y0 = bt601(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
-            const uint32_t y1 = bt601(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
-            const uint32_t y2 = bt601((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
-            const uint32_t y3 = bt601((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
-            reinterpret_cast<uint32_t*>(drow)[i] = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
-        } else if (i == quads) {
-            for (uint32_t x = quads << 2; x < width; ++x) {
-                const uint8_t* px = srow + (int64_t)x * 3;
-                drow[x] = (uint8_t)bt601(px[0], px[1], px[2]);
-            }
-        }
-    } else {
+    if constexpr (PX == 0) {
         for (uint32_t x = i; x < width; x += gridDim.x * blockDim.x) {
             const uint8_t* px = srow + (int64_t)x * src_step;
             drow[x] = (uint8_t)bt601(px[0], px[1], px[2]);
+        }
+    } else {
+        const uint32_t quads = width >> 2;
+        if (i < quads) {
+            const u32_any* p = reinterpret_cast<const u32_any*>(srow + (size_t)i * (4 * PX));
+            uint32_t y0, y1, y2, y3;
+            if constexpr (PX == 3) {
+                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];    // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+                y0 = bt601(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+                y1 = bt601(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+                y2 = bt601((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+                y3 = bt601((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+            } else {
+                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];    // R G B x, one pixel per dword
+                y0 = bt601(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+                y1 = bt601(w1 & 255u, (w1 >> 8) & 255u, (w1 >> 16) & 255u);
+                y2 = bt601(w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u);
+                y3 = bt601(w3 & 255u, (w3 >> 8) & 255u, (w3 >> 16) & 255u);
+            }
+            *reinterpret_cast<u32_any*>(drow + 4 * (size_t)i) = y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+        } else if (i == quads) {
+            for (uint32_t x = quads << 2; x < width; ++x) {
+                const uint8_t* px = srow + (int64_t)x * PX;
+                drow[x] = (uint8_t)bt601(px[0], px[1], px[2]);
+            }
         }
     }
 }
@@ -1296,11 +1313,12 @@ hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src
                             uint32_t width, uint32_t height, hipStream_t stream)
 {
     if (width == 0 || height == 0) return hipSuccess;
-    const bool packed = src_step == 3 && ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)src_stride) & 3u) == 0 &&
-                        ((reinterpret_cast<uintptr_t>(dst) | (uintptr_t)dst_stride) & 3u) == 0;
-    const uint32_t items = packed ? (width >> 2) + 1 : width;
+    const bool quad = src_step == 3 || src_step == 4;
+    const uint32_t items = quad ? (width >> 2) + 1 : width;
     const dim3 grid((items + 255) / 256, height), block(256);
-    hipLaunchKernelGGL(luminance_kernel, grid, block, 0, stream, dst, dst_stride, src, src_step, src_stride, width, height, packed ? 1 : 0);
+    if (src_step == 3)      hipLaunchKernelGGL(luminance_kernel<3>, grid, block, 0, stream, dst, dst_stride, src, src_step, src_stride, width, height);
+    else if (src_step == 4) hipLaunchKernelGGL(luminance_kernel<4>, grid, block, 0, stream, dst, dst_stride, src, src_step, src_stride, width, height);
+    else                    hipLaunchKernelGGL(luminance_kernel<0>, grid, block, 0, stream, dst, dst_stride, src, src_step, src_stride, width, height);
     return hipGetLastError();
 }
 
