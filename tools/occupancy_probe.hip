@@ -22,10 +22,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
-enum { S_INDEP = 0, S_CHAIN2, S_CHAIN1, S_RINGADD, S_LDS, S_FMA32, S_CVTUB, S_RCP, S_CVTF64, S_ADDF64, S_LDS1, S_LDS2, S_LDS4, S_LDS2_B64, S_COUNT };
+enum { S_INDEP = 0, S_CHAIN2, S_CHAIN1, S_RINGADD, S_LDS, S_FMA32, S_CVTUB, S_RCP, S_CVTF64, S_ADDF64, S_LDS1, S_LDS2, S_LDS4, S_LDS2_B64, S_VMEM2, S_VMEM4, S_LDSW4, S_LDSW4_B32, S_LDSW4_B128, S_LDSW4_2B64, S_LDSW4_2B32, S_COUNT };
 static const char* kStream[] = {"indep pk_fma", "chain6 x2 interleaved", "chain6 x1 back to back", "ring pk_add shift", "indep pk_fma + ds_read_b128/12 (+ uses)",
                                 "v_fma_f32 (unpacked)", "v_cvt_f32_ubyte0", "v_rcp_f32", "v_cvt_f64_f32", "v_add_f64",
-                                "24 pk_fma + 1 ds_read_b128 (no use)", "24 pk_fma + 2 ds_read_b128 (no use)", "24 pk_fma + 4 ds_read_b128 (no use)", "24 pk_fma + 4 ds_read_b64 (no use)"};
+                                "24 pk_fma + 1 ds_read_b128 (no use)", "24 pk_fma + 2 ds_read_b128 (no use)", "24 pk_fma + 4 ds_read_b128 (no use)", "24 pk_fma + 4 ds_read_b64 (no use)",
+                                "24 pk_fma + 2 global_load_ubyte (no use)", "24 pk_fma + 4 global_load_ubyte (no use)", "24 pk_fma + 4 ds_write_b64", "24 pk_fma + 4 ds_write_b32", "24 pk_fma + 4 ds_write_b128", "24 pk_fma + 4 ds_write2_b64", "24 pk_fma + 4 ds_write2_b32"};
 
 // W waves per SIMD -> the register the kernel pretends to use
 template <int W> __device__ __forceinline__ void pad_registers()
@@ -112,6 +113,34 @@ __global__ __launch_bounds__(64) void probe(float* out, int iters, float seed)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k = 0; k < NR; ++k) { if constexpr (STREAM == S_LDS2_B64) asm volatile("" :: "v"(r2[k])); else asm volatile("" :: "v"(r[k])); }
+        } else if constexpr (STREAM == S_VMEM2 || STREAM == S_VMEM4) {
+            // byte loads (the pixel fetches of the row loop: a wave-uniform base + a lane offset, L2 hits here) between the packed instructions
+            constexpr int NR = STREAM == S_VMEM2 ? 2 : 4;
+            unsigned r[4];
+            const unsigned off = threadIdx.x + 64u * (i & 15);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j < NR) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(r[j]) : "v"(off), "s"(out));
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < NR; ++k) asm volatile("" :: "v"(r[k]));
+        } else if constexpr (STREAM == S_LDSW4 || STREAM == S_LDSW4_B32 || STREAM == S_LDSW4_B128 || STREAM == S_LDSW4_2B64 || STREAM == S_LDSW4_2B32) {
+            const unsigned addr = (threadIdx.x * (STREAM == S_LDSW4_B128 ? 16u : STREAM == S_LDSW4_B32 || STREAM == S_LDSW4_2B32 ? 4u : 8u)) & 1023u;
+            const f4 a4 = {a.x, a.y, b.x, b.y};
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j < 4) {
+                    if constexpr (STREAM == S_LDSW4)           asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(a) : "memory");
+                    else if constexpr (STREAM == S_LDSW4_B32)  asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(a.x) : "memory");
+                    else if constexpr (STREAM == S_LDSW4_B128) asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(a4) : "memory");
+                    else if constexpr (STREAM == S_LDSW4_2B64) asm volatile("ds_write2_b64 %0, %1, %2 offset1:144" :: "v"(addr), "v"(a), "v"(b) : "memory");
+                    else                                       asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(a.x), "v"(a.y) : "memory");
+                }
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[j]) : "v"(a), "v"(b));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -187,5 +216,12 @@ int main()
     if (sweep<S_LDS2>(d_out, cus, ghz)) return 1;
     if (sweep<S_LDS4>(d_out, cus, ghz)) return 1;
     if (sweep<S_LDS2_B64>(d_out, cus, ghz)) return 1;
+    if (sweep<S_VMEM2>(d_out, cus, ghz)) return 1;
+    if (sweep<S_VMEM4>(d_out, cus, ghz)) return 1;
+    if (sweep<S_LDSW4>(d_out, cus, ghz)) return 1;
+    if (sweep<S_LDSW4_B32>(d_out, cus, ghz)) return 1;
+    if (sweep<S_LDSW4_B128>(d_out, cus, ghz)) return 1;
+    if (sweep<S_LDSW4_2B64>(d_out, cus, ghz)) return 1;
+    if (sweep<S_LDSW4_2B32>(d_out, cus, ghz)) return 1;
     return 0;
 }
