@@ -207,6 +207,28 @@ def make_partial_hybrid(aa_bb_ref, ab_ref):
     return f
 
 
+def form_hybrid_four(a, b):
+    """round 4 study: MODE_FAST with E[a^2] and E[b^2] merged into ONE reference-order plane E[a^2 + b^2] (four planes, 169 lane-ops)"""
+    a = a.astype(f32); b = b.astype(f32)
+    muA, muB = blur_sep(a), blur_sep(b)
+    muA2, muB2, muAB = muA * muA, muB * muB, muA * muB
+    eS, eAB = blur_ref(a * a + b * b), blur_ref(a * b)
+    num = (f32(2) * muAB + C1) * (f32(2) * (eAB - muAB) + C2)
+    den = ((muA2 + muB2) + C1) * ((eS - (muA2 + muB2)) + C2)
+    return (num / den).astype(f32)
+
+
+def form_hybrid_four_split(a, b):
+    """the same with the reference's association of the variance sum: (E[a^2 + b^2] - mu_a^2) - mu_b^2"""
+    a = a.astype(f32); b = b.astype(f32)
+    muA, muB = blur_sep(a), blur_sep(b)
+    muA2, muB2, muAB = muA * muA, muB * muB, muA * muB
+    eS, eAB = blur_ref(a * a + b * b), blur_ref(a * b)
+    num = (f32(2) * muAB + C1) * (f32(2) * (eAB - muAB) + C2)
+    den = ((muA2 + muB2) + C1) * (((eS - muA2) - muB2) + C2)
+    return (num / den).astype(f32)
+
+
 FORMS = {
     "ref": (form_ref, "the reference's order in this model (validates the model: 0 pixels differ)"),
     "MODE_FAST": (mode_fast, "shipped: reference-order E planes, separable mu planes (centre first)"),
@@ -219,6 +241,8 @@ FORMS = {
     "five planes centred": (form_centred_five, "five planes on centred pixels"),
     "fast, E[ab] separable": (make_partial_hybrid(True, False), "MODE_FAST with only E[a^2], E[b^2] in the reference's order"),
     "fast, E[a^2] E[b^2] separable": (make_partial_hybrid(False, True), "MODE_FAST with only E[ab] in the reference's order"),
+    "hybrid, E[a^2 + b^2] one plane": (form_hybrid_four, "round 4: MODE_FAST with the two variance planes merged into one reference-order plane"),
+    "hybrid, one plane, split subtraction": (form_hybrid_four_split, "the same, (E - mu_a^2) - mu_b^2"),
     "ref mu + exact E": (form_refmu_exactE, "attribution: only the reference's mu rounding"),
     "exact mu + ref E": (form_exactmu_refE, "attribution: only the reference's E rounding"),
 }
