@@ -54,11 +54,13 @@ def main():
     s = open(sys.argv[1]).read()
     bench = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else None
     kernels = [("exact", "ssim_strip2_kernelILi0ELi0ELb0EE", 2, 278), ("fast (hybrid)", "ssim_strip2_kernelILi1ELi0ELb0EE", 2, 220),
-               ("separable", "ssim_strip2_kernelILi4ELi0ELb0EE", 3, 119)]
+               ("separable", "ssim_strip2_kernelILi4ELi0ELb0EE", 3, 119), ("double + map (one column per lane: a row = 64 pixels)", "ssim_strip1_kernelILi2ELb1ELb0EE", 3, 137)]
     measured = {}
     if bench:
         W, H, pairs = bench["config"]["width"], bench["config"]["height"], bench["config"]["pairs_per_gpu"]
         measured = {"exact": bench["roofline"]["kernel_avg_ms"], "fast (hybrid)": bench["fast_mode"]["kernel_avg_ms"], "separable": bench["separable_mode"]["kernel_avg_ms"]}
+        dbl = bench.get("configs", {}).get("4k double + map")
+        if dbl: measured["double + map (one column per lane: a row = 64 pixels)"] = dbl["kernel_avg_ms"]
     print("| kernel (main loop, per ROW of a wave = 128 pixels) | waves/SIMD | packed | unpacked | cvt | f64 | rcp | LDS reads | LDS writes | VMEM | model clk | of it blur arithmetic | measured clk | measured / model |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name, sym, waves, ops in kernels:
@@ -73,14 +75,18 @@ def main():
             if k: c[k] += 1
         per_row = {k: v / 2.0 for k, v in c.items()}          # the loop body is two rows
         clk = sum(per_row[k] * COST[k][waves] for k in per_row)
-        blur = {"exact": 255, "fast (hybrid)": 197, "separable": 88}[name]     # packed instructions of the blur streams per row and lane (= lane-ops per pixel)
-        blur_clk = blur * COST["pk"][waves]
+        if name.startswith("double"):
+            blur_clk = 88 * COST["f64"][waves]       # the fp64 multiply-adds of the four blur streams + formula per row and lane
+        else:
+            blur = {"exact": 255, "fast (hybrid)": 197, "separable": 88}[name]     # packed instructions of the blur streams per row and lane (= lane-ops per pixel)
+            blur_clk = blur * COST["pk"][waves]
         meas = ""
         ratio = ""
         if name in measured:
             # wave-rows of the launch: strips x (rows + 10 warm-up); strips of 512 rows at these sizes
             strips_y = (H + 511) // 512
-            wave_rows = pairs * ((W + 127) // 128) * strips_y * ((H + strips_y - 1) // strips_y + 10)
+            n_pairs, strip_w = (4, 64) if name.startswith("double") else (pairs, 128)      # the fp64 config of the bench line is 4 x 4096^2
+            wave_rows = n_pairs * ((W + strip_w - 1) // strip_w) * strips_y * ((H + strips_y - 1) // strips_y + 10)
             mc = measured[name] * 1e-3 * 2.375e9 * 1024 / wave_rows
             meas, ratio = "%.0f" % mc, "%.2f" % (mc / clk)
         print("| %s | %d | %g | %g | %g | %g | %g | %g | %g | %g | %.0f | %.0f (%.0f %%) | %s | %s |" % (
