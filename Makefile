@@ -24,9 +24,14 @@ lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim-hip-double.so $(OUT)/librmgr
 # internal ssim_hip:: interface between the ABI layer and the kernels would otherwise be visible to -- and collide with --
 # whatever else the program links; the reference's archive exposes its API only).  A program that links it also needs the
 # HIP runtime: g++ app.o -lrmgr-ssim -L/opt/rocm/lib -lamdhip64 -ldl -lpthread
+# --force-group-allocation: the objects carry COMDAT groups (inline functions, typeinfo, guard variables of the C++ runtime
+# headers).  A plain `ld -r` keeps the groups and objcopy below then makes their symbols LOCAL; a client object that carries
+# a group of the same signature (anything using std::make_shared, std::thread, ...) makes the final link discard the
+# archive's copy and leaves its now-local references dangling ("defined in discarded section").  Allocated into ordinary
+# sections here, the archive's copies are private to it and always kept.
 $(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
 	@mkdir -p $(OUT)
-	ld -r -o $(OBJ)/rmgr_ssim_api.o $^
+	ld -r --force-group-allocation -o $(OBJ)/rmgr_ssim_api.o $^
 	objcopy --wildcard --keep-global-symbol='rmgr_ssim_*' --keep-global-symbol='_ZN4rmgr4ssim12compute_ssimE*' --keep-global-symbol='_ZN4rmgr4ssim11select_implE*' $(OBJ)/rmgr_ssim_api.o
 	rm -f $@ && ar rcs $@ $(OBJ)/rmgr_ssim_api.o
 

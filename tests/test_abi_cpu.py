@@ -5,6 +5,7 @@ import ctypes
 import errno
 import os
 import re
+import shutil
 import subprocess
 import sys
 
@@ -54,6 +55,23 @@ def test_static_archive_exposes_nothing_but_the_api():
     exported = set(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3)
     allowed = declared_c_functions() | set(ssim_amd.CXX_SYMBOLS)
     assert exported == allowed, (sorted(exported - allowed), sorted(allowed - exported))
+
+
+@pytest.mark.parametrize("cxx", ["g++", "/opt/rocm/lib/llvm/bin/clang++"])
+def test_static_archive_links_into_modern_cxx_programs(tmp_path, cxx):
+    """the archive's single relocatable object must survive a client that carries the same COMDAT
+    groups (std::make_shared, std::thread, unique_lock, vector, exceptions): built with g++ / ld.bfd and with clang++,
+    -O2, and run (no device here: the call reports ENODEV; on the GPU box it computes)."""
+    if not os.path.exists(cxx) and shutil.which(cxx) is None:
+        pytest.skip(cxx + " not installed")
+    archive = os.path.join(os.path.dirname(ssim_amd.LIB_PATH), "librmgr-ssim.a")
+    exe = tmp_path / "cxx17_client"
+    subprocess.run([cxx, "-std=c++17", "-O2", "-Wall", "-I", INCLUDE, os.path.join(ROOT, "tests", "cxx17_client.cpp"), "-o", str(exe),
+                    archive, "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert out[1] == "16" and int(out[0]) in (0, errno.ENODEV), out
+    if not has_gpu():
+        assert int(out[0]) == errno.ENODEV
 
 
 def test_struct_layouts_match_reference_abi():
