@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libssim_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libssim_ref.so")
+REF_DOUBLE_SO = os.path.join(_HERE, "_ref", "libssim_ref_double.so")   # the reference's RMGR_SSIM_USE_DOUBLE build
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _f32p = ctypes.POINTER(ctypes.c_float)
@@ -27,6 +28,7 @@ def build(quiet=True):
 
 _oracle = None
 _ref = None
+_ref_double = None
 
 
 def oracle_lib():
@@ -56,6 +58,34 @@ def oracle_lib():
 
 def have_ref():
     return os.path.exists(REF_SO)
+
+
+def have_ref_double():
+    return os.path.exists(REF_DOUBLE_SO)
+
+
+def _bind_ref(path):
+    lib = ctypes.CDLL(path)
+    lib.ref_compute_ssim.restype = ctypes.c_int
+    lib.ref_compute_ssim.argtypes = [_f32p, _f64p, ctypes.c_uint32, ctypes.c_uint32,
+                                     ctypes.c_void_p, _pd, _pd, ctypes.c_void_p, _pd, _pd,
+                                     ctypes.c_void_p, _pd, _pd, ctypes.c_int, ctypes.c_int]
+    lib.ref_naive_f64.restype = ctypes.c_double
+    lib.ref_naive_f64.argtypes = [ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_void_p, _pd, _pd, ctypes.c_void_p, _pd, _pd,
+                                  ctypes.c_void_p, _pd, _pd]
+    lib.ref_max_threads.restype = ctypes.c_int
+    lib.ref_is_double.restype = ctypes.c_int
+    return lib
+
+
+def ref_double_lib():
+    """The reference's fp64 flavour: the same kernels compiled with Float = double (oracle/Makefile)."""
+    global _ref_double
+    if _ref_double is None:
+        _ref_double = _bind_ref(REF_DOUBLE_SO)
+        assert _ref_double.ref_is_double() == 1
+    return _ref_double
 
 
 def ref_lib():
@@ -149,9 +179,10 @@ def ssim_naive_f64(a, b, want_map=False, threads=1):
     return out.value, s.value, m
 
 
-def ref_ssim(a, b, want_map=False, impl=5, threads=1, out_map=None):
+def ref_ssim(a, b, want_map=False, impl=5, threads=1, out_map=None, double=False):
     """REAL reference kernels (oracle/_ref).  impl 5 = FMA, 4 = AVX.  out_map: write the map into this H x W float32 array
-    (timing loops: a fresh 268 MB array per call measures the kernel's page faults, not the path)."""
+    (timing loops: a fresh 268 MB array per call measures the kernel's page faults, not the path).
+    double=True: the RMGR_SSIM_USE_DOUBLE flavour (fp64 internals; the map is float there too)."""
     a = np.ascontiguousarray(a)
     b = np.ascontiguousarray(b)
     h, w = a.shape
@@ -161,7 +192,7 @@ def ref_ssim(a, b, want_map=False, impl=5, threads=1, out_map=None):
         assert out_map.shape == (h, w) and out_map.dtype == np.float32 and out_map.flags.c_contiguous
         want_map = True
     m = (out_map if out_map is not None else np.empty((h, w), np.float32)) if want_map else None
-    rc = ref_lib().ref_compute_ssim(ctypes.byref(out), ctypes.byref(s), w, h,
+    rc = (ref_double_lib() if double else ref_lib()).ref_compute_ssim(ctypes.byref(out), ctypes.byref(s), w, h,
                                     _addr(a), 1, a.strides[0], _addr(b), 1, b.strides[0],
                                     _addr(m) if want_map else None, 1, w, impl, threads)
     if rc:

@@ -17,7 +17,20 @@
  * generates; per the build rules that makes the driver TU unbuildable here, so this harness
  * re-creates just the driver's buffer choreography (src/ssim.cpp:747-783, :1026-1103) around
  * the real kernels.  The halo fetch uses the reference's own naive::retrieve_tile template,
- * which is the same algorithm as src/ssim.cpp:515-583.
+ * which is the same algorithm as src/ssim.cpp:515-583 (the same statements, instantiated for
+ * Float / uint8_t).
+ *
+ * Two flavours, like the reference's own build (CMakeLists.txt:53, src/ssim_internal.h:33-37):
+ *   _ref/libssim_ref.so          Float = float   (default)
+ *   _ref/libssim_ref_double.so   Float = double  (-DRMGR_SSIM_USE_DOUBLE=1 on all three TUs): tiles are 128 wide
+ *                                (src/ssim.cpp:230), the map stays float, and with a map the driver takes its GENERIC
+ *                                sum_tile (src/ssim.cpp:947-950) -- a static function of the unbuildable TU, restated
+ *                                below as sum_tile_generic (per-pixel expressions and summation grouping of :590-704).
+ *
+ * Scratch: the driver's default is six buffers ON THE STACK of whichever thread runs the tile
+ * (process_tile_on_stack, src/ssim.cpp:786-791) -- no allocation, no clearing; this harness does the same.
+ * (Round 4 allocated and zeroed 549 KB per thread and call.)  Threads: `omp parallel for` with the default (static)
+ * schedule and per-thread fp64 partials added in thread order, as src/ssim-openmp.c:26-37 + src/ssim.cpp:911-926, :1098.
  */
 #include "ssim_internal.h"   // from /root/reference/src (via -I)
 #include "ssim_naive.h"      // from /root/reference/tests (via -I)
@@ -35,7 +48,7 @@ typedef rmgr::ssim::Float Float;
 
 // src/ssim.cpp:227-239
 const uint32_t kRadius     = 5;
-const uint32_t kTileW      = 256;
+const uint32_t kTileW      = 256 / (sizeof(Float) / sizeof(float));   // src/ssim.cpp:230
 const uint32_t kTileH      = 64;
 const uint32_t kVertMargin = 2 * kRadius;
 const size_t   kRowAlign   = 64 / sizeof(Float);
@@ -50,6 +63,52 @@ struct Job {
     float* map; ptrdiff_t mapStep, mapStride;
     rmgr::ssim::GaussianBlurFct blur;
 };
+
+#if RMGR_SSIM_USE_DOUBLE
+// Restatement of the driver's generic sum_tile (src/ssim.cpp:590-704) for the one case the SIMD sum_tile does not cover:
+// the double build WITH a map.  Per pixel: mu products, sigma = E - mu*mu, ((2 muAB + c1)(2 sAB + c2)) / ((muA2 + muB2 + c1)
+// (sA2 + sB2 + c2)), the map element is float(ssim); per row, pixels 4k+j go to row sum j (j = 0..3), added to the tile sum
+// as (r0 + r1) + (r2 + r3), then the up-to-three left-over pixels one by one.
+double sum_tile_generic(uint32_t tw, uint32_t th, uint32_t ts, Float c1, Float c2, const Float* muA, const Float* muB,
+                        const Float* eA2, const Float* eB2, const Float* eAB, float* map, ptrdiff_t mapStep, ptrdiff_t mapStride)
+{
+    struct Px {
+        static Float at(size_t i, Float c1, Float c2, const Float* muA, const Float* muB, const Float* eA2, const Float* eB2, const Float* eAB)
+        {
+            const Float a = muA[i], b = muB[i];
+            const Float a2 = a * a, b2 = b * b, ab = a * b;
+            const Float sA2 = eA2[i] - a2, sB2 = eB2[i] - b2, sAB = eAB[i] - ab;
+            const Float num = (2 * ab + c1) * (2 * sAB + c2);
+            const Float den = (a2 + b2 + c1) * (sA2 + sB2 + c2);
+            return num / den;
+        }
+    };
+    double total = 0.0;
+    for (uint32_t y = 0; y < th; ++y) {
+        const size_t o = size_t(y) * ts;
+        float* out = map ? map + ptrdiff_t(y) * mapStride : NULL;
+        const uint32_t quads = tw & ~3u;
+        uint32_t x = 0;
+        if (quads) {
+            double r[4] = {0.0, 0.0, 0.0, 0.0};
+            for (; x < quads; ++x) {
+                const Float v = Px::at(o + x, c1, c2, muA, muB, eA2, eB2, eAB);
+                r[x & 3u] += v;
+                if (out)
+                    out[ptrdiff_t(x) * mapStep] = float(v);
+            }
+            total += (r[0] + r[1]) + (r[2] + r[3]);
+        }
+        for (; x < tw; ++x) {
+            const Float v = Px::at(o + x, c1, c2, muA, muB, eA2, eB2, eAB);
+            total += v;
+            if (out)
+                out[ptrdiff_t(x) * mapStep] = float(v);
+        }
+    }
+    return total;
+}
+#endif
 
 // src/ssim.cpp:747-783 (process_tile): same six-buffer layout and aliasing, real kernels.
 double run_tile(const Job& jb, Float* buffers, uint32_t tileX, uint32_t tileY)
@@ -89,7 +148,18 @@ double run_tile(const Job& jb, Float* buffers, uint32_t tileX, uint32_t tileY)
     const Float c1 = Float((0.01 * 255.0) * (0.01 * 255.0));
     const Float c2 = Float((0.03 * 255.0) * (0.03 * 255.0));
     float* mapTile = jb.map ? jb.map + tileX * jb.mapStep + tileY * jb.mapStride : NULL;
+#if RMGR_SSIM_USE_DOUBLE
+    if (mapTile)      // src/ssim.cpp:947-950
+        return sum_tile_generic(tw, th, ts, c1, c2, muA, muB, sA2, sB2, sAB, mapTile, jb.mapStep, jb.mapStride);
+#endif
     return rmgr::ssim::avx::g_sumTileFct(tw, th, ts, c1, c2, muA, muB, sA2, sB2, sAB, mapTile, jb.mapStep, jb.mapStride);
+}
+
+// src/ssim.cpp:786-791 (process_tile_on_stack)
+double run_tile_on_stack(const Job& jb, uint32_t tileX, uint32_t tileY)
+{
+    alignas(64) Float buffers[6 * kBufCapacity];
+    return run_tile(jb, buffers, tileX, tileY);
 }
 
 } // namespace
@@ -118,30 +188,21 @@ int ref_compute_ssim(float* ssim, double* sumOut, uint32_t width, uint32_t heigh
         threads = 1;
     threads = std::min(threads, 64); // src/ssim.cpp:1025
     std::vector<double> partial(threads, 0.0);
-    int err = 0;
-#pragma omp parallel num_threads(threads)
-    {
+    if (threads == 1) {       // the serial walk of src/ssim.cpp:1081-1084
+        for (uint32_t ty = 0; ty < height; ty += kTileH)
+            for (uint32_t tx = 0; tx < width; tx += kTileW)
+                partial[0] += run_tile_on_stack(jb, tx, ty);
+    } else {
+#pragma omp parallel for num_threads(threads)
+        for (int64_t t = 0; t < tiles; ++t) {
 #ifdef _OPENMP
-        const int tn = omp_get_thread_num();
+            const int tn = omp_get_thread_num();
 #else
-        const int tn = 0;
+            const int tn = 0;
 #endif
-        void* mem = NULL;
-        if (posix_memalign(&mem, 64, 6 * kBufCapacity * sizeof(Float)) != 0) {
-#pragma omp atomic write
-            err = 12;
-        } else {
-            memset(mem, 0, 6 * kBufCapacity * sizeof(Float));
-            double local = 0.0;
-#pragma omp for schedule(static)
-            for (int64_t t = 0; t < tiles; ++t)
-                local += run_tile(jb, static_cast<Float*>(mem), uint32_t(t % tilesX) * kTileW, uint32_t(t / tilesX) * kTileH);
-            partial[tn] = local;
-            free(mem);
+            partial[tn] += run_tile_on_stack(jb, uint32_t(t % tilesX) * kTileW, uint32_t(t / tilesX) * kTileH);
         }
     }
-    if (err)
-        return err;
     double sum = 0.0;
     for (int t = 0; t < threads; ++t)
         sum += partial[t];
@@ -159,6 +220,12 @@ double ref_naive_f64(uint32_t width, uint32_t height,
                      double* map, ptrdiff_t mapStep, ptrdiff_t mapStride)
 {
     return rmgr::ssim::naive::compute_ssim<double, uint8_t>(width, height, a, aStep, aStride, b, bStep, bStride, map, mapStep, mapStride);
+}
+
+/* 1 when this library is the RMGR_SSIM_USE_DOUBLE flavour */
+int ref_is_double(void)
+{
+    return RMGR_SSIM_USE_DOUBLE ? 1 : 0;
 }
 
 int ref_max_threads(void)

@@ -196,6 +196,58 @@ def test_double_mode_4k_config5(gpu_ctx, oracle, manifest):
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
 
 
+def test_double_mode_vs_the_references_own_double_build(gpu_ctx, manifest, oracle):
+    """BASELINE.json configs[4] against what the reference's RMGR_SSIM_USE_DOUBLE build itself returns (tests/golden/ref_double.json:
+    src/ssim_fma.cpp + src/ssim_avx.cpp compiled with Float = double; tests/tools/make_double_fixtures.py, tests/test_ref_double.py).
+    That build keeps float-typed tap literals and is up to 4.8e-7 / 3.8e-6 (global / per pixel) away from
+    tests/ssim_naive.h<double> on these pairs; MODE_DOUBLE is within 6e-8 / 1e-7 of naive<double> (tests above), so
+    |MODE_DOUBLE - double build| is the double build's own error.  Asserted: inside the reference's test tolerances for its
+    double build (tests/rmgr-ssim-tests.cpp:98-100: 5e-7 / 1e-5), and inside the measured maxima with a small margin."""
+    import json
+    with open(os.path.join(GOLDEN, "ref_double.json")) as f:
+        rd = json.load(f)
+    live = oracle.have_ref_double()           # the prebuilt checker travels to the GPU box: then EVERY pixel of every pair
+    gpu_ctx.set_mode(ssim_amd.MODE_DOUBLE)
+    worst_g = worst_p = 0.0
+    keep = []
+    try:
+        for name in image_entries(manifest):
+            ent, ref = manifest[name], rd["pairs"][name]
+            a, b = load_pair(ent)
+            v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
+            worst_g = max(worst_g, abs(float(v) - float(ref["mean"])))       # v: the float the call returns (<= 3e-8 of rounding)
+            rmap = None
+            if "map" in ref:
+                rmap = np.load(os.path.join(GOLDEN, ref["map"]))
+            elif live:
+                _, _, rmap = oracle.ref_ssim(a, b, want_map=True, impl=5, double=True)
+            if rmap is not None:
+                worst_p = max(worst_p, float(np.abs(m.astype(np.float64) - rmap.astype(np.float64)).max()))
+        # the 4096^2 pair of configs[4]
+        ref = rd["synth4096_5eed"]
+        a, b = oracle.synth_pair(4096, 4096, 0x5EED)
+        da, db, dm = gpu_ctx.upload(a), gpu_ctx.upload(b), gpu_ctx.alloc(4 * 4096 * 4096)
+        keep += [da, db, dm]
+        v = gpu_ctx.compute_device(ssim_amd.make_params(4096, 4096, da.ptr, 1, 4096, db.ptr, 1, 4096, dm.ptr, 1, 4096))
+        m = dm.download(np.float32, (4096, 4096))
+        g4k = abs(float(v) - float(ref["mean"]))
+        sample = np.load(os.path.join(GOLDEN, ref["map_sample"]))
+        p4k = float(np.abs(m.reshape(-1)[::ref["map_sample_step"]].astype(np.float64) - sample.astype(np.float64)).max())
+        if live:
+            _, _, rmap = oracle.ref_ssim(a, b, want_map=True, impl=5, threads=oracle.oracle_lib().oracle_max_threads(), double=True)
+            for y in range(0, 4096, 512):
+                p4k = max(p4k, float(np.abs(m[y:y + 512].astype(np.float64) - rmap[y:y + 512].astype(np.float64)).max()))
+        print("MODE_DOUBLE vs the reference's double build: fixtures global %.3e pixel %.3e; 4096^2 global %.3e pixel %.3e (%s)"
+              % (worst_g, worst_p, g4k, p4k, "every pixel, live _ref" if live else "committed maps / samples"))
+        assert max(worst_g, g4k) <= 5e-7 and max(worst_p, p4k) <= 1e-5           # the reference's tolerances for its double build
+        assert worst_g <= 4.9e-7 + 6e-8 and worst_p <= 3.9e-6 + 1e-7                # its measured error + MODE_DOUBLE's own (float result / map)
+        assert g4k <= 5.4e-8 + 6e-8 and p4k <= 8.8e-7 + 1e-7
+    finally:
+        for d in keep:
+            d.free()
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+
+
 def test_process_wide_mode_switch(manifest):
     """RMGR_SSIM_HIP_MODE selects the arithmetic of the unchanged drop-in call (what RMGR_SSIM_USE_DOUBLE
     does at build time in the reference, src/ssim_internal.h:26-37): mode 2 must return the double-mode value."""
