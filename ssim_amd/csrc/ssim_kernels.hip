@@ -337,14 +337,25 @@ __device__ __forceinline__ double ssim_px_four(double muA, double muB, double eS
 // Scalar form (the one-column kernel); the packed form below performs the same operations on both columns of a lane, so
 // the two kernels agree bit for bit.
 constexpr float kCentre = 128.0f;
+// Round 5: n / d as n * rcp(d) in this mode.  It is not bit-exact against anything (its contract: the reference's TEST tolerances
+// against the exact value, include/rmgr/ssim-hip.h); v_rcp_f32 is accurate to 1 ulp and the product adds half an ulp: <= 1.8e-7 of a
+// value in [-1, 1], three orders of magnitude inside the mode's per-pixel budget, for 3 instead of 9 instructions per two pixels
+// (the correctly rounded sequence of div_inrange_*: one Newton step on the reciprocal, two quotient corrections).  d is in
+// [2^8, 2^35] as before (ssim_px2_head): no scaling, no special cases.  What was tried with it and dropped (tests/tools/
+// fast_mode_model.py, profiles/r05_separable_epilogue.md): expanding the luminance terms around the centre
+// (2 mu_a mu_b + c1 = 2 m_a m_b + 256 (m_a + m_b) + 2 * 128^2 + c1, two packed and two scalar operations fewer) cancels
+// catastrophically in dark areas -- 4.1e-4 per pixel on bbb360 against 1.5e-4 --, and mu_a^2 + mu_b^2 = (m_a - m_b)^2 + 2 m_a m_b
+// keeps the per-pixel error but biases the global value (1.4e-6 on the bbb crops against 8.7e-7).
+// Scalar form (the one-column kernel); the packed form below performs the same operations on both columns of a lane, so
+// the two kernels agree bit for bit.
 __device__ __forceinline__ float ssim_px_sep(float mA, float mB, float eS, float eX, float c1, float c2)
 {
     const float sS = eS - (mA * mA + mB * mB), sAB = eX - mA * mB;       // from the centred moments
     const float muA = mA + kCentre, muB = mB + kCentre;
     const float muAB = muA * muB, tm = muA * muA + muB * muB;
-    const f2 n = {__builtin_fmaf(2.0f, muAB, c1) * __builtin_fmaf(2.0f, sAB, c2), 0.0f};
-    const f2 d = {(tm + c1) * (sS + c2), 1.0f};
-    return div_inrange_finish(n, d, div_inrange_rcp(d)).x;
+    const float n = __builtin_fmaf(2.0f, muAB, c1) * __builtin_fmaf(2.0f, sAB, c2);
+    const float d = (tm + c1) * (sS + c2);
+    return n * __builtin_amdgcn_rcpf(d);
 }
 // m0, m1 = centred (mu_a', mu_b') of the lane's two columns; e0, e1 = (E[a'^2 + b'^2], E[a'b']) of the two columns
 __device__ __forceinline__ f2 ssim_px2_sep(f2 m0, f2 m1, f2 e0, f2 e1, float c1, float c2)
@@ -362,7 +373,8 @@ __device__ __forceinline__ f2 ssim_px2_sep(f2 m0, f2 m1, f2 e0, f2 e1, float c1,
     const f2 two = {2.0f, 2.0f}, C1 = {c1, c1}, C2 = {c2, c2};
     const f2 n = fma_(two, muAB, C1) * fma_(two, sAB, C2);
     const f2 den = (tm + C1) * (sS + C2);
-    return div_inrange_finish(n, den, div_inrange_rcp(den));      // operand ranges as for ssim_px2_head/tail
+    const f2 r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    return n * r;
 }
 
 struct KArgs {
@@ -529,8 +541,12 @@ __device__ __forceinline__ void cell_batch_flush1(const KArgs& args, const Strip
 
 // ---------------------------------------------------------------------------------------------
 // ssim_strip2_kernel -- the default kernel of the fp32 modes: two adjacent columns per lane,
-// 128-column strips.  LDS slot = one source row with 8 px of halo each side (5 needed; 8 keeps
-// every wide read naturally aligned): (a,b) pairs, (a*a,b*b) pairs, and the ab plane stored as
+// 128-column strips.  LDS slot = one source row of 144 pixels starting SEVEN columns left of the strip
+// (round 5; 5 are needed, rounds 1-4 had 8): the twelve window pixels of a lane's two columns -- columns
+// x-5 .. x+6, slot pixels 2 lane + 2 .. 2 lane + 13 -- then start on an even slot pixel and are exactly six
+// naturally aligned 16-byte reads per plane; with an even left halo they straddle seven, the first and last
+// half unused (20 -> 18 window reads per row in the five-plane modes, 14 -> 12 in MODE_SEPARABLE, and 4
+// window registers fewer per plane).  Planes: (a,b) pairs, (a*a,b*b) pairs, and the ab plane stored as
 // pairs xx[p] = (ab[p], ab[p+1]) so that ALL five blur streams are packed-fp32 code on naturally
 // aligned register pairs (no v_pk_mov shuffles), fed by 16-byte ds_read_b128.
 // Tried and dropped (measured on MI355X, round 1): refilling each plane's window for row r+1 right
@@ -540,7 +556,7 @@ __device__ __forceinline__ void cell_batch_flush1(const KArgs& args, const Strip
 // copy moves to the oldest entry instead; unrolling over the two LDS slots is what removes it).
 // ---------------------------------------------------------------------------------------------
 struct Slot2 {
-    static constexpr int STRIP_W = 128, PAD = 8, ROW_PX = STRIP_W + 2 * PAD;
+    static constexpr int STRIP_W = 128, PAD = 7, ROW_PX = 144;      // PAD: halo columns left of the strip (odd: see above); 137 + 5 pixels are used
     f2 ab[ROW_PX];   // (a, b)
     f2 q[ROW_PX];    // (a*a, b*b)
     f2 xx[ROW_PX];   // (ab[p], ab[p+1])
@@ -635,9 +651,17 @@ void ssim_strip2_kernel(const KArgs args)
         float* xf = reinterpret_cast<float*>(s.xx);
 #pragma unroll
         for (int t = 0; t < NLOAD; ++t) {
-            float a = (float)ia[t], b = (float)ib[t];         // retrieve_tile: uint8 -> Float
-            if constexpr (FAST) { a -= kCentre; b -= kCentre; }   // centred pixels (ssim_px_sep); exact
-            const f2 ab = {a, b};
+            f2 ab;
+            if constexpr (FAST) {
+                // conversion and centring by bit pattern (round 5): 0x4B0000bb is the float 2^23 + bb, and ONE packed subtraction of
+                // 2^23 + 128 turns both into the centred pixels (ssim_px_sep) -- exact; v_or_b32 x 2 + v_pk_add_f32 instead of
+                // v_cvt_f32_ubyte0 x 2 + v_sub_f32 x 2 (9.9 against 14.5 clk at this kernel's three waves per SIMD)
+                const f2 biased = {__builtin_bit_cast(float, 0x4B000000u | (uint32_t)ia[t]), __builtin_bit_cast(float, 0x4B000000u | (uint32_t)ib[t])};
+                ab = biased - f2{8388736.0f, 8388736.0f};
+            } else {
+                ab = f2{(float)ia[t], (float)ib[t]};          // retrieve_tile: uint8 -> Float
+            }
+            const float a = ab.x, b = ab.y;
             const float x = a * b;                            // multiply (exact for 8-bit inputs)
             const int p = sp[t];
             s.ab[p] = ab;
@@ -684,16 +708,13 @@ void ssim_strip2_kernel(const KArgs args)
         if constexpr (MAP != 0) offM[c] = col_ok[c] ? (uint32_t)((int64_t)(x - refM) * pd.map_step * 4) : 0x80000000u;
     }
 
-    // Window registers.  Column 0 needs window pixels 1..11, column 1 needs 2..12 (index 0 = slot pixel
-    // 2*lane+2): the two end pixels are 8-byte reads, the ten in between five 16-byte reads.  Only what is
-    // used is loaded (a dead half of a wide read gets its register reused and forces an early s_waitcnt).
-    f2 wab[14], wq[14], wxx[12];
-    const int e = 2 * lane + PAD - 6;                   // even: the 16-byte reads are aligned
+    // Window registers.  Index 0 = slot pixel 2 lane + 2 = image column x - 5 of the lane's first column x: column 0 needs
+    // window pixels 0..10 (centre 5), column 1 needs 1..11 (centre 6): six 16-byte reads, every half of which is used.
+    f2 wab[12], wq[12], wxx[12];
+    const int e = 2 * lane + PAD - 5;                   // even: the 16-byte reads are aligned
     auto load_ab = [&](const Slot2& s) {
-        // seven 16-byte reads; entries 0 and 13 are not used but are kept alive up to the folds (below):
-        // as 8-byte end reads the compiler moves them to the top of the loop, where their latency is exposed
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
+        for (int t = 0; t < 6; ++t) {
             const f4 v = *reinterpret_cast<const f4*>(&s.ab[e + 2 * t]);
             wab[2 * t] = v.xy; wab[2 * t + 1] = v.zw;
         }
@@ -710,12 +731,11 @@ void ssim_strip2_kernel(const KArgs args)
     auto fold_ab = [&]() {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const int m = 6 + c;
+            const int m = 5 + c;
             ca[c] = wab[m];
 #pragma unroll
             for (int i = 1; i <= 5; ++i) fa[c][i - 1] = wab[m + i] + wab[m - i];   // s[x+i]+s[x-i], src/ssim_fma.cpp:196-201
         }
-        asm volatile("" :: "v"(wab[0]), "v"(wab[13]));   // see load_ab
         if constexpr (HYB || FAST) {
             const f2 s0[6] = {ca[0], fa[0][0], fa[0][1], fa[0][2], fa[0][3], fa[0][4]};
             const f2 s1[6] = {ca[1], fa[1][0], fa[1][1], fa[1][2], fa[1][3], fa[1][4]};
@@ -762,10 +782,11 @@ void ssim_strip2_kernel(const KArgs args)
         __builtin_amdgcn_s_setprio(2);
         // (1), (2) request the other two planes of this row
         __builtin_amdgcn_sched_barrier(0);
-        // Whole 16-byte reads only: 8-byte reads at this 16-byte lane stride are 2-way bank conflicts.  The three
-        // end entries the wide form loads without need are kept alive until their planes are consumed (see load_ab).
+        // Whole 16-byte reads only: 8-byte reads at this 16-byte lane stride are 2-way bank conflicts.  The one end entry
+        // the wide form loads without need (the last of the ab plane's pairs) is kept alive until its plane is consumed: a dead
+        // half of a wide read gets its register reused and forces an early s_waitcnt.
 #pragma unroll
-        for (int t = 0; t < 7; ++t) {
+        for (int t = 0; t < 6; ++t) {
             const f4 u = *reinterpret_cast<const f4*>(&s.q[e + 2 * t]);
             wq[2 * t] = u.xy;  wq[2 * t + 1] = u.zw;
         }
@@ -792,17 +813,16 @@ void ssim_strip2_kernel(const KArgs args)
         if constexpr (!FAST) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const int m = 6 + c;
+                const int m = 5 + c;
                 const f2 q1 = wq[m + 1] + wq[m - 1], q2 = wq[m + 2] + wq[m - 2], q3 = wq[m + 3] + wq[m - 3],
                          q4 = wq[m + 4] + wq[m - 4], q5 = wq[m + 5] + wq[m - 5];
                 blur_exact<FUSED, KMIN>(accQ[c], wq[m], q1, q2, q3, q4, q5);
             }
-            asm volatile("" :: "v"(wq[0]), "v"(wq[13]), "v"(wxx[0]));
+            asm volatile("" :: "v"(wxx[11]));
         } else {
-            const f2 s0[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
-            const f2 s1[6] = {wq[7], wq[8] + wq[6], wq[9] + wq[5], wq[10] + wq[4], wq[11] + wq[3], wq[12] + wq[2]};
+            const f2 s0[6] = {wq[5], wq[6] + wq[4], wq[7] + wq[3], wq[8] + wq[2], wq[9] + wq[1], wq[10] + wq[0]};
+            const f2 s1[6] = {wq[6], wq[7] + wq[5], wq[8] + wq[4], wq[9] + wq[3], wq[10] + wq[2], wq[11] + wq[1]};
             blur_separable_pair<ORDER_CENTRE_FIRST, KMIN>(accQ[0], accQ[1], s0, s1, gf);
-            asm volatile("" :: "v"(wq[0]), "v"(wq[13]));
         }
         Px2 head;
         if constexpr (!FAST) {
@@ -814,9 +834,9 @@ void ssim_strip2_kernel(const KArgs args)
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (phase != ROW_WARMUP)
                 head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
-            // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 6
-            const f2 x1 = wxx[7] + wxx[5], x2 = wxx[8] + wxx[4], x3 = wxx[9] + wxx[3], x4 = wxx[10] + wxx[2], x5 = wxx[11] + wxx[1];
-            blur_exact<FUSED, KMIN>(accX, wxx[6], x1, x2, x3, x4, x5);
+            // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 5
+            const f2 x1 = wxx[6] + wxx[4], x2 = wxx[7] + wxx[3], x3 = wxx[8] + wxx[2], x4 = wxx[9] + wxx[1], x5 = wxx[10] + wxx[0];
+            blur_exact<FUSED, KMIN>(accX, wxx[5], x1, x2, x3, x4, x5);
         }
         __builtin_amdgcn_sched_barrier(0);
 

@@ -145,11 +145,51 @@ def mode_fast(a, b, order=CENTRE):
 
 
 def mode_separable(a, b, c=128.0, om=CENTRE, oe=CENTRE):
+    """round 5: the kernels form the quotient as n * rcp(d) with the hardware's 1-ulp reciprocal, which is not reproducible here:
+    this model divides exactly and the kernels are compared with it to 3 ulp (tests/test_gpu_modes.py)"""
     a = a.astype(f32) - f32(c); b = b.astype(f32) - f32(c)
     mA, mB = blur_sep(a, GT, om), blur_sep(b, GT, om)
     sS = blur_sep(a * a + b * b, GT, oe) - (mA * mA + mB * mB)
     sAB = blur_sep(a * b, GT, oe) - mA * mB
     return px4(mA + f32(c), mB + f32(c), sS, sAB)
+
+
+def px4_centred_expanded(mA, mB, eS, eX, c=128.0):
+    """round 5, tried and DROPPED: luminance terms expanded around the centre -- 2 mu_a mu_b + c1 = fma(2c, s, fma(2, pc, K1)),
+    mu_a^2 + mu_b^2 + c1 = fma(2c, s, tc + K1) with s = m_a + m_b, pc = m_a m_b, tc = m_a^2 + m_b^2, K1 = 2 c^2 + c1: two packed and
+    two scalar operations fewer per pixel pair, but in dark areas 2 pc + 2c s + 2 c^2 cancels catastrophically: 4.1e-4 per pixel
+    on bbb360 (the shipped form: 1.5e-4)."""
+    k1 = f32(np.float64(2.0 * c * c) + np.float64(0.01 * 255.0) ** 2)
+    tc = mA * mA + mB * mB
+    pc = mA * mB
+    ss = mA + mB
+    sS, sAB = eS - tc, eX - pc
+    nl = fma(f32(2 * c), ss, fma(f32(2), pc, k1))
+    dl = fma(f32(2 * c), ss, tc + k1)
+    n = nl * fma(f32(2), sAB, C2)
+    d = dl * (sS + C2)
+    return (n / d).astype(f32)
+
+
+def form_separable_expanded(a, b, c=128.0):
+    a = a.astype(f32) - f32(c); b = b.astype(f32) - f32(c)
+    return px4_centred_expanded(blur_sep(a), blur_sep(b), blur_sep(a * a + b * b), blur_sep(a * b), c)
+
+
+def form_separable_difference(a, b, c=128.0):
+    """round 5, tried and DROPPED: mu_a^2 + mu_b^2 as (m_a - m_b)^2 + 2 m_a m_b and the luminance denominator as numerator +
+    (m_a - m_b)^2: four packed operations fewer per pixel pair, per-pixel error unchanged, but the global value picks up a
+    bias (1.4e-6 on the bbb crops against 8.7e-7)."""
+    a = a.astype(f32) - f32(c); b = b.astype(f32) - f32(c)
+    mA, mB, eS, eX = blur_sep(a), blur_sep(b), blur_sep(a * a + b * b), blur_sep(a * b)
+    d = mA - mB
+    dd = d * d
+    pc = mA * mB
+    tc = fma(f32(2), pc, dd)
+    ln = fma(f32(2), (mA + f32(c)) * (mB + f32(c)), C1)
+    n = ln * fma(f32(2), eX - pc, C2)
+    den = (ln + dd) * ((eS - tc) + C2)
+    return (n / den).astype(f32)
 
 
 # ---- the forms that were studied and not shipped ----------------------------------------------------------------------
@@ -239,6 +279,8 @@ FORMS = {
     "five planes, r2 orders": (make_five(INNER, SMALL), "five planes with round 2's orders"),
     "four planes, r2 orders": (make_four(INNER, SMALL), "round 2's MODE_FAST"),
     "five planes centred": (form_centred_five, "five planes on centred pixels"),
+    "separable, luminance expanded": (form_separable_expanded, "round 5 (dropped): MODE_SEPARABLE with the luminance terms expanded around the centre"),
+    "separable, difference form": (form_separable_difference, "round 5 (dropped): MODE_SEPARABLE with mu_a^2 + mu_b^2 = (m_a - m_b)^2 + 2 m_a m_b"),
     "fast, E[ab] separable": (make_partial_hybrid(True, False), "MODE_FAST with only E[a^2], E[b^2] in the reference's order"),
     "fast, E[a^2] E[b^2] separable": (make_partial_hybrid(False, True), "MODE_FAST with only E[ab] in the reference's order"),
     "hybrid, E[a^2 + b^2] one plane": (form_hybrid_four, "round 4: MODE_FAST with the two variance planes merged into one reference-order plane"),
