@@ -46,7 +46,8 @@ class Params(ctypes.Structure):
 class Plan(ctypes.Structure):
     _fields_ = [("structSize", ctypes.c_uint32), ("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
                 ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32), ("waveSlots", ctypes.c_uint32), ("earlyRowSums", ctypes.c_uint32),
-                ("cellRows", ctypes.c_uint32), ("cellsX", ctypes.c_uint32), ("cellsY", ctypes.c_uint32)]
+                ("cellRows", ctypes.c_uint32), ("cellsX", ctypes.c_uint32), ("cellsY", ctypes.c_uint32),
+                ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32)]
 
 
 ABI_VERSION = 4      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against

@@ -685,6 +685,8 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_
     full.cellRows = geo.cell_rows;
     full.cellsX = geo.cells_x;
     full.cellsY = geo.cells_y;
+    full.balancedChunks = geo.n_chunks;
+    full.balancedChunkRows = geo.chunk_cells * geo.cell_rows;
     memcpy(plan, &full, std::min<size_t>(plan->structSize, sizeof(full)));      // never beyond what the caller allocated
     return 0;
 }

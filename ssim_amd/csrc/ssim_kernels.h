@@ -33,6 +33,8 @@ struct Geometry {
     bool     map_unit;            // every pair of the launch writes its map with ssimStep == 1 (set by the caller of plan(); scheduling only)
     bool     wide;                // some pair needs the fully 64-bit form of the one-column kernel (!fits_strip2(); set by the caller of plan())
     uint32_t wave_slots;          // strips the chip holds at a time with this kernel (SIMDs x waves per SIMD): plan()'s packing unit
+    uint32_t chunk_cells;         // > 0: the balanced schedule of the two-column kernel -- every wavefront covers this many cell rows of the launch's
+    uint32_t n_chunks;            //      flattened [image][strip column][cell row] list (n_chunks wavefronts); 0: one strip per wavefront
     uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 
@@ -96,7 +98,7 @@ inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8
 inline bool uses_early_row_sums(const Geometry& geo, int mode, int variant)
 {
     if ((mode != MODE_EXACT && mode != MODE_UNFUSED) || variant == 1 || geo.strip_w != 128) return false;
-    if (variant == 3) return true;
+    if (variant == 3 || variant == 6) return true;      // 6: the balanced schedule, which exists with EARLY row sums only
     if (variant != 0) return false;
     const uint64_t strips = (uint64_t)geo.strips_x * geo.strips_y * geo.count;
     return geo.wave_slots != 0 && strips <= 3ull * geo.wave_slots;

@@ -384,6 +384,10 @@ struct KArgs {
     uint32_t        y_begin, y_end;   // output rows of this launch (a multiple-of-8 start; the whole image unless the host pipelines bands)
     uint32_t        cells_x, cells_y; // the image's grid of 64-column x cell_rows-row cells: the units of the fp64 reduction
     uint32_t        cell_shift;       // log2(cell_rows): 3 or 5 by image height (cell_rows_for())
+    uint32_t        col_cells;    // cell rows of one strip column inside [y_begin, y_end)
+    uint32_t        chunk_cells;  // 0: one strip per workgroup (grid strips_x x strips_y x count); > 0: the BALANCED schedule -- workgroup w covers cell rows
+                                  // [w * chunk_cells, ...) of the launch's flattened [image][strip column][cell row] list, continuing into the next column / image
+    uint32_t        n_chunks;     // workgroups of the balanced schedule (1-D grid)
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
@@ -459,6 +463,60 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     st.x0 = (int64_t)st.sx * strip_w;
     st.y0 = (int64_t)args.y_begin + (int64_t)st.sy * args.strip_rows;
     st.y_end = (st.y0 + args.strip_rows < (int64_t)args.y_end) ? st.y0 + args.strip_rows : (int64_t)args.y_end;
+    return st;
+}
+
+// BALANCED schedule of the two-column kernel (round 5; prototyped in round 4: profiles/r04_balanced_schedule_ab.txt).  plan()'s strips
+// quantise: 128 x 1080p are 1920 strip columns x 1080 rows on 2048 wave slots; the best split, three 360-row strips per column, is
+// 5760 strips = 2.81 rounds of 372 row-times = 1116 against 1012.5 if the work were spread evenly.  Here the launch's cell rows are
+// flattened [image][strip column][cell row] and cut into `wave slots` equal chunks; a wavefront walks its chunk SEGMENT by segment
+// (a segment = the part inside one strip column: what a strip is), continuing into the next strip column or image.  Cells, maps
+// and sums are the strips' bit for bit.  It pays where the strips leave a partial round and LOSES elsewhere (a static equal
+// partition needs every SIMD to run at the same speed for the whole launch): which launches take it is plan()'s measured rule.
+// The work of one wavefront: `n` cell rows starting at cell row `cy` of strip column `sx` of image `img`.
+struct Work { uint32_t img, sx, cy, n; };
+
+__device__ __forceinline__ Work work_setup(const KArgs& args)
+{
+    Work w;
+    // each XCD walks a contiguous eighth of the chunk list (strip_setup)
+    const uint32_t b = blockIdx.x, total = args.n_chunks;
+    const uint32_t xcd = b & 7u, slot = b >> 3, q = total >> 3, rem = total & 7u;
+    const uint32_t id = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    const uint32_t all = args.count * args.strips_x * args.col_cells;      // < 2^31 (plan())
+    const uint32_t first = id * args.chunk_cells;
+    w.n = all - first < args.chunk_cells ? all - first : args.chunk_cells;
+    const uint32_t col = first / args.col_cells;
+    w.cy = first - col * args.col_cells;
+    w.img = col / args.strips_x;
+    w.sx = col - w.img * args.strips_x;
+    return w;
+}
+
+// The next segment of `w` as a Strip; advances `w`.
+__device__ __forceinline__ Strip segment_setup(const KArgs& args, Work& w, int strip_w)
+{
+    Strip st;
+    st.img = w.img; st.sx = w.sx; st.sy = 0;
+    st.pd = args.single;
+    if (args.descs) {
+        const gptr_desc gd = (gptr_desc)args.descs + st.img;
+        st.pd.a = (const uint8_t*)uniform64((int64_t)gd->a); st.pd.a_step = uniform64(gd->a_step); st.pd.a_stride = uniform64(gd->a_stride);
+        st.pd.b = (const uint8_t*)uniform64((int64_t)gd->b); st.pd.b_step = uniform64(gd->b_step); st.pd.b_stride = uniform64(gd->b_stride);
+        st.pd.map = (float*)uniform64((int64_t)gd->map); st.pd.map_step = uniform64(gd->map_step); st.pd.map_stride = uniform64(gd->map_stride);
+    }
+    const uint32_t seg = args.col_cells - w.cy < w.n ? args.col_cells - w.cy : w.n;
+    st.W = args.width; st.H = args.height;
+    st.x0 = (int64_t)st.sx * strip_w;
+    st.y0 = (int64_t)args.y_begin + ((int64_t)w.cy << args.cell_shift);
+    const int64_t ye = st.y0 + ((int64_t)seg << args.cell_shift);
+    st.y_end = ye < (int64_t)args.y_end ? ye : (int64_t)args.y_end;
+    w.n -= seg;
+    w.cy += seg;
+    if (w.cy == args.col_cells) {
+        w.cy = 0;
+        if (++w.sx == args.strips_x) { w.sx = 0; ++w.img; }
+    }
     return st;
 }
 
@@ -585,7 +643,8 @@ enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 // the fold at the bottom of the previous iteration, in the wave's low-priority phase, and cross the loop edge instead of
 // the folded sums (24 registers either way); the high-priority phase then only scatters them into the ring.  Same
 // operations, same bits.  It pays on launches of few rounds of wave slots and costs on long ones (see launch()).
-template <int MODE, int MAP, bool EARLY = false>
+// BAL (bit-exact modes without a map, with EARLY): the balanced schedule (work_setup above) -- the body below in a segment loop.
+template <int MODE, int MAP, bool EARLY = false, bool BAL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_SEPARABLE ? 3 : 2, MODE == MODE_SEPARABLE ? 3 : 2)))
 void ssim_strip2_kernel(const KArgs args)
 {
@@ -603,7 +662,13 @@ void ssim_strip2_kernel(const KArgs args)
     // the separable taps as six scalars (an array inside the kernel argument block, passed on by reference, can end up
     // in scratch memory when scalar and packed streams both use it)
     const float gf[6] = {args.gf[0], args.gf[1], args.gf[2], args.gf[3], args.gf[4], args.gf[5]};
-    const Strip st = strip_setup(args, Slot2::STRIP_W);
+    Work wk = {0, 0, 0, 0};
+    if constexpr (BAL) wk = work_setup(args);
+#pragma unroll 1
+    do {                                // BAL: one pass per segment of the wavefront's chunk; otherwise once: the wavefront's strip
+    Strip st;
+    if constexpr (BAL) st = segment_setup(args, wk, Slot2::STRIP_W);
+    else               st = strip_setup(args, Slot2::STRIP_W);
     const PairDesc& pd = st.pd;
     // 32-bit coordinates (fits_strip2() on the host guarantees the ranges): row bookkeeping stays on the
     // scalar unit -- there are no 64-bit scalar ordered compares, so int64 loop counters cost VALU work.
@@ -938,6 +1003,8 @@ void ssim_strip2_kernel(const KArgs args)
         wave_sync();
         cell_batch_flush2(args, st, cells, cell_y, parked);
     }
+    if constexpr (BAL) wave_sync();     // the next segment re-uses the LDS slots and the cell batch
+    } while (BAL && wk.n != 0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1239,6 +1306,10 @@ hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStre
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
     if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
+        if (geo.chunk_cells != 0 && !map) {          // the balanced schedule (plan()): bit-exact modes, no map, EARLY row sums
+            hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, true, true>), dim3(geo.n_chunks, 1, 1), block, 0, stream, ka);
+            return hipGetLastError();
+        }
         if (early) {
             if (!map)              hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, true>), grid, block, 0, stream, ka);
             else if (geo.map_unit) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 2, true>), grid, block, 0, stream, ka);
@@ -1410,6 +1481,8 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.y_end = (y_rows >= height - g.y_begin) ? height : g.y_begin + y_rows;
     const uint32_t rows_total = g.y_end - g.y_begin;
     auto round_cell = [cr](uint32_t v) { return (v + cr - 1) & ~(cr - 1); };      // up to whole cells
+    const bool default_rows = strip_rows <= 0;
+    uint64_t strips_cost = 0;          // the chosen strips under the packing model below (row-times x 1000); 0: not modelled
     if (strip_rows <= 0 && rows_total > 0) {
         // Default: the strip height with the lowest cost under a DISCRETE model of how the launch's n strips (of u =
         // rows + 10 halo rows + ~2 rows of setup each) pack onto the chip's wave slots -- fitted to strip-height sweeps
@@ -1440,10 +1513,38 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
             if (cost < best) { best = cost; best_rows = rows; }
         }
         strip_rows = (int)best_rows;
+        strips_cost = best;
     }
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries
     g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
+    // The balanced schedule (work_setup()): the bit-exact two-column kernel without a map (launch_strip2() checks the map).  Tuning
+    // variant 6 forces it.  By default it is taken where the packing model prices the strips at least 7 % above one round of equal
+    // chunks AND a chunk is at most 1100 rows: measured with strips and chunks interleaved on one box over 32 launch shapes
+    // (profiles/r05_balanced_sweep.txt), the chunks run ~5.5 % slower than this model says (a static equal partition needs every
+    // SIMD to run at the same speed for the whole launch; the strips' later rounds absorb the differences), more for long chunks:
+    // the rule picks 24 / 40 / 48 / 64 / 96 / 128 x 1080p (+4.0 / +5.2 / +5.7 / +4.0 / +1.2 / +2.1 %) and 3 x 4096^2 (+4.8 %), and leaves
+    // alone everything the chunks lose on (8 x 1080p -7 %, 12 / 24 x 4096^2 -3 / -5 %, 192...384 x 1080p -2...-3.5 %) or only tie.
+    g.chunk_cells = 0; g.n_chunks = 0;
+    if ((mode == MODE_EXACT || mode == MODE_UNFUSED) && g.strip_w == 128 && rows_total > 0 && (variant == 6 || (variant == 0 && default_rows))) {
+        const uint64_t col_cells = (rows_total + cr - 1) / cr, all = (uint64_t)count * g.strips_x * col_cells;
+        const uint64_t want = g.wave_slots;
+        if (all > want && all < (1ull << 31)) {
+            const uint64_t chunk = (all + want - 1) / want, n_chunks = (all + chunk - 1) / chunk;
+            bool take = variant == 6;
+            if (!take && strips_cost != 0 && chunk * cr <= 1100) {
+                // one round of n_chunks <= wave slots chunks of chunk x cell rows, + 12 row-times per segment (1 + chunk / col_cells of them)
+                const uint64_t simds = (uint64_t)(cu_count > 0 ? cu_count : 256) * 4;
+                const uint64_t tail = n_chunks > simds ? 1000 : 685;
+                const uint64_t chunks_cost = (chunk * cr * col_cells + 12 * (col_cells + chunk)) * tail / col_cells;
+                take = strips_cost * 100 >= chunks_cost * 107;
+            }
+            if (take) {
+                g.chunk_cells = (uint32_t)chunk;
+                g.n_chunks = (uint32_t)n_chunks;
+            }
+        }
+    }
     return g;
 }
 
@@ -1487,6 +1588,9 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.y_begin = geo.y_begin; ka.y_end = geo.y_end;
     ka.cells_x = geo.cells_x; ka.cells_y = geo.cells_y;
     ka.cell_shift = geo.cell_rows == 32 ? 5 : geo.cell_rows == 16 ? 4 : 3;
+    ka.col_cells = geo.y_end > geo.y_begin ? (geo.y_end - geo.y_begin + geo.cell_rows - 1) / geo.cell_rows : 0;
+    ka.chunk_cells = geo.chunk_cells;
+    ka.n_chunks = geo.n_chunks;
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;

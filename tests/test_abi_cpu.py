@@ -314,9 +314,16 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == errno.EINVAL
     buf[0] = 64                                                         # a client from the future: only what this library knows is written
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0
-    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and all(v == 0xDEADBEEF for v in buf[11:])
+    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 0 and buf[12] == 0 and all(v == 0xDEADBEEF for v in buf[13:])
     p = ssim_amd.get_plan(1920, 1080, 1)
     assert (p.cellRows, p.cellsX, p.cellsY) == (8, 30, 135)
+    # round 5: the balanced schedule (one round of equal chunks instead of strips) is the default exactly where the strips leave a
+    # partial round worth recovering (profiles/r05_balanced_sweep.txt): configs[3]'s per-GPU share yes, the headline batch no
+    p = ssim_amd.get_plan(1920, 1080, 128)
+    assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (5760, 2041, 1016)
+    assert p.balancedChunks * p.balancedChunkRows >= 128 * 15 * 1080            # the chunks cover every row of every strip column
+    for (w, h, n) in [(4096, 4096, 32), (4096, 4096, 1), (8192, 8192, 2), (1920, 1080, 1024), (1920, 1080, 256), (256, 256, 1)]:
+        assert ssim_amd.get_plan(w, h, n).balancedChunks == 0, (w, h, n)
 
 
 def test_kernels_keep_two_waves_per_simd_and_never_spill():
@@ -340,9 +347,9 @@ def test_kernels_keep_two_waves_per_simd_and_never_spill():
             if m and name:
                 kernels[name][key.split(" ")[0]] = int(m.group(1))
     strip = {k: v for k, v in kernels.items() if "ssim_strip" in k}
-    # two-column kernel: 4 fp32 modes x {no map, map, map with 8-byte stores} + the EARLY form of the two bit-exact modes;
-    # one-column kernel: 5 modes x {no map, map} x {64-bit, 32-bit addressing}
-    assert len(strip) == 38, sorted(kernels)
+    # two-column kernel: 4 fp32 modes x {no map, map, map with 8-byte stores} + the EARLY form of the two bit-exact modes + their
+    # balanced-schedule form (no map, EARLY); one-column kernel: 5 modes x {no map, map} x {64-bit, 32-bit addressing}
+    assert len(strip) == 40, sorted(kernels)
     for k, v in strip.items():
         assert v["ScratchSize"] == 0, (k, v)
         assert v["VGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)

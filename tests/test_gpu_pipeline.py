@@ -185,6 +185,52 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
             d.free()
 
 
+@pytest.mark.parametrize("shape", [(640, 360, 120), (130, 2049, 20), (1920, 1080, 24), (257, 65, 700)],
+                         ids=["8-row-cells", "32-row-cells-short-last", "default-rule-1080p", "many-small"])
+def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
+    """Round 5: the balanced schedule of the bit-exact two-column kernel (launches without a map: one round of equal chunks of the
+    flattened [image][strip column][cell row] list, wavefronts continuing into the next strip column or image) must give the strips'
+    per-image fp64 sums bit for bit -- forced (tuning variant 6) and as plan()'s default choice -- on hostile values, in both
+    bit-exact modes, for chunk boundaries inside images, at image ends and with short last cells."""
+    w, h, n = shape
+    rng = np.random.default_rng(w * 7 + h + n)
+    base = hostile_pairs(rng, w, h, 6)
+    pairs = [base[i % 6] if i % 7 else (base[i % 6][1], base[(i + 1) % 6][0]) for i in range(n)]      # n pairs out of 6 x 2 uploaded planes
+    keep = []
+    try:
+        planes = {}
+        params = (ssim_amd.Params * n)()
+        for i, (a, b) in enumerate(pairs):
+            for img in (a, b):
+                if id(img) not in planes:
+                    planes[id(img)] = gpu_ctx.upload(img)
+                    keep.append(planes[id(img)])
+            params[i] = ssim_amd.make_params(w, h, planes[id(a)].ptr, 1, w, planes[id(b)].ptr, 1, w)
+        sums = gpu_ctx.alloc(8 * n)
+        keep.append(sums)
+        for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED):
+            gpu_ctx.set_mode(mode)
+            res = {}
+            for variant, rows in ((2, 0), (3, 0), (6, 0), (0, 0), (6, 64), (2, 8)):
+                gpu_ctx.set_tuning(rows, variant)
+                if variant == 6:
+                    assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0, "the shape is meant to engage the balanced schedule"
+                sums.upload(np.zeros(n))
+                gpu_ctx.enqueue_batch(params, n, sums.ptr)
+                gpu_ctx.synchronize()
+                res[(variant, rows)] = bits64(sums.download(np.float64, (n,)))
+            for key, got in res.items():
+                assert np.array_equal(got, res[(2, 0)]), (mode, key, int((got != res[(2, 0)]).sum()))
+        gpu_ctx.set_tuning(0, 0)
+        if shape == (1920, 1080, 24):
+            assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0        # plan()'s default for this shape (on a 256-CU device)
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+        for d in keep:
+            d.free()
+
+
 @pytest.mark.parametrize("size", [(1500, 1090), (2100, 2300), (4096, 4100)], ids=["8-row-cells", "32-row-cells", "two-reduce-chunks"])
 def test_row_bands_on_separate_contexts_equal_one_launch(gpu_ctx, size):
     """SURVEY.md 8(e), "single huge image across GPUs": one pair cut into row bands (rmgr_ssim_hip_enqueue_rows), every band

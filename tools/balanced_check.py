@@ -1,0 +1,35 @@
+"""The balanced schedule (tuning variant 6) against the strips (variants 2, 3): per-image fp64 sums of batches without a map, bit for bit,
+over sizes (ragged, shorter than a cell, many cells), batch sizes, both bit-exact modes and strip heights.  Run on the GPU box."""
+import sys, numpy as np
+sys.path.insert(0, '.')
+import ssim_amd
+ctx = ssim_amd.Context(0)
+rng = np.random.default_rng(11)
+bad = 0
+for (w, h, n) in [(256, 256, 1), (300, 301, 3), (1, 1, 5), (17, 5, 40), (129, 64, 7), (1920, 1080, 3), (1920, 1080, 40), (4096, 4096, 2), (1000, 37, 33),
+                  (130, 2049, 9), (640, 360, 300), (255, 63, 128), (2048, 2048, 5)]:
+    keep, params = [], (ssim_amd.Params * n)()
+    for i in range(n):
+        a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        b = np.clip(a.astype(np.int32) + rng.integers(-40, 41, (h, w)), 0, 255).astype(np.uint8)
+        da, db = ctx.upload(a), ctx.upload(b)
+        keep += [da, db]
+        params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, None, 1, w)
+    ds = ctx.alloc(8 * n)
+    for mode in (0, 3):
+        ctx.set_mode(mode)
+        res = {}
+        for v in (2, 3, 6, 0):
+            for rows in (0, 8, 64):
+                ctx.set_tuning(rows, v)
+                ds.upload(np.zeros(n, np.float64))
+                ctx.enqueue_batch(params, n, ds.ptr); ctx.synchronize()
+                res[(v, rows)] = ds.download(np.float64, (n,)).copy().view(np.uint64)
+        ref = res[(2, 0)]
+        for k, sm in res.items():
+            if not np.array_equal(sm, ref):
+                bad += 1; print("MISMATCH", w, h, n, mode, k, int((sm != ref).sum()))
+    for d in keep + [ds]: d.free()
+print("balanced schedule check: mismatches", bad)
+ctx.close()
+sys.exit(1 if bad else 0)
