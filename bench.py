@@ -174,8 +174,7 @@ def cpu_baseline(budget_s=10.0):
     per = {"4k": {"pixels": px, "map": False, "threads_all_mpix_s": round(px / min(ts) / 1e6, 1),
                   "threads_all_median_mpix_s": round(px / statistics.median(ts) / 1e6, 1),
                   "one_thread_mpix_s": round(px / min(t1) / 1e6, 1)}}
-    # 8192^2 with map (configs[2]) and one 1080p pair (configs[3]'s image); double build: see DESIGN.md (the
-    # reference's fp64 SIMD path is not part of oracle/_ref, so configs[4] has no "reference" CPU number)
+    # 8192^2 with map (configs[2]) and one 1080p pair (configs[3]'s image)
     for name, (w, h, want_map, kat) in (("8k-map", (8192, 8192, True, WORKLOADS["8k-map"][5][0])),
                                         ("1080p", (1920, 1080, False, WORKLOADS["1080p"][5][0]))):
         aa, bb = oracle.synth_pair(w, h, 0x5EED)
@@ -188,6 +187,32 @@ def cpu_baseline(budget_s=10.0):
                      "threads_all_median_mpix_s": round(w * h / statistics.median(ta) / 1e6, 1),
                      "one_thread_mpix_s": round(w * h / min(to) / 1e6, 1)}
         del aa, bb, r, mm
+    # configs[3] as BASELINE.md section 3 defines its CPU figure: the 1024 x 1080p batch looped SERIALLY over pairs with OpenMP inside
+    # each call (the reference's harness shape, tests/rmgr-ssim-tests.cpp:293-303).  32 distinct pairs (seeds 0x5EED + i) are timed,
+    # twice; the rate is per pixel, so the 1024-pair figure is the same number (stated, not measured, for pairs 33..1024).
+    batch_pairs = [oracle.synth_pair(1920, 1080, 0x5EED + i) for i in range(32)]
+    def batch_pass():
+        for aa, bb in batch_pairs:
+            run(aa, bb, cores)
+    batch_pass()
+    tb = timed(batch_pass, 0.0, min_runs=2)
+    per["1080p-batch"] = {"pixels": 32 * 1920 * 1080, "map": False, "pairs_timed": 32, "pairs_in_config": 1024, "loop": "serial over pairs, OpenMP inside each call",
+                          "threads_all_mpix_s": round(32 * 1920 * 1080 / min(tb) / 1e6, 1),
+                          "seconds_for_1024_pairs_extrapolated": round(min(tb) * 32, 2)}
+    del batch_pairs
+    # configs[4]: the reference's RMGR_SSIM_USE_DOUBLE build (oracle/_ref/libssim_ref_double.so: the same TUs with Float = double), 4096^2 with and
+    # without the map; with a map that build takes its generic sum_tile (src/ssim.cpp:947-950), restated in oracle/ref_harness.cpp
+    if kind == "reference" and oracle.have_ref_double():
+        rund = lambda threads, mm=None: oracle.ref_ssim(a, b, impl=5, threads=threads, out_map=mm, double=True)
+        assert int(np.float32(rund(cores)[0]).view(np.uint32)) == WORKLOADS["4k"][5][0], "CPU baseline (double build) disagrees with the known answer"
+        mm = np.zeros((H, W), np.float32)
+        td, tdm = timed(lambda: rund(cores), 1.5), timed(lambda: rund(cores, mm), 1.5)
+        td1 = timed(lambda: rund(1), 0.0, min_runs=1)
+        per["4k-double"] = {"pixels": px, "build": "RMGR_SSIM_USE_DOUBLE=1 (oracle/_ref/libssim_ref_double.so)",
+                            "threads_all_mpix_s": round(px / min(td) / 1e6, 1), "threads_all_median_mpix_s": round(px / statistics.median(td) / 1e6, 1),
+                            "with_map_threads_all_mpix_s": round(px / min(tdm) / 1e6, 1), "with_map_threads_all_median_mpix_s": round(px / statistics.median(tdm) / 1e6, 1),
+                            "one_thread_mpix_s": round(px / min(td1) / 1e6, 1)}
+        del mm
     model, procs = host_cpu()
     pinning = ", ".join("%s=%s" % (k, os.environ[k]) for k in sorted(CPU_BASELINE_ENV) if os.environ.get(k)) or "unpinned"
     return {"value": round(px / min(ts) / 1e6, 1), "median": round(px / statistics.median(ts) / 1e6, 1), "unit": "Mpix/s",
@@ -198,7 +223,12 @@ def cpu_baseline(budget_s=10.0):
                       "median = median run (the figure to quote); per_config: best of ~2 s (all threads) / of 1-2 runs (1 thread) on one pair of each image size; %s"
                       % (len(ts), budget_s, cores, pinning,
                          "the reference's real FMA/AVX kernel objects (oracle/_ref: src/ssim_fma.cpp, src/ssim_avx.cpp compiled as they are) driven by "
-                         "the tile loop of oracle/ref_harness.cpp -- NOT by src/ssim.cpp, which needs a cmake-generated header -- OpenMP static schedule over tiles"
+                         "the tile loop of oracle/ref_harness.cpp -- NOT by src/ssim.cpp, which needs a cmake-generated header -- scratch on the executing thread's stack "
+                         "and OpenMP's default schedule over tiles as the reference's default path; in the build container this leg runs at the cmake-built reference's "
+                         "speed to within that container's run-to-run spread (BASELINE.md 2b: 79-92 / 530-558 Mpix/s at 1 / 8 threads on 4096^2 against 83.1 / 532: "
+                         "-5...+11 % per row at one thread, best runs equal at eight, medians 20 % lower); per_config['1080p-batch'] is configs[3] as BASELINE.md "
+                         "section 3 defines it (pairs looped serially, OpenMP inside each call; 32 of the 1024 pairs timed), per_config['4k-double'] the reference's "
+                         "RMGR_SSIM_USE_DOUBLE build (configs[4])"
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
@@ -238,13 +268,16 @@ def attainable_hbm_gbs(torch, dev):
     return round(2.0 * n / (best * 1e-3) / 1e9, 1)
 
 
-def kernel_name(mode, variant, want_map, early=False):
+def kernel_name(mode, variant, want_map, plan=None):
     """Template instance rocprofv3 lists for this configuration (ssim_kernels.hip): the two-column kernel's second argument
     is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even), its third whether the bit-exact modes run their
-    EARLY form (short launches; rmgr_ssim_hip_get_plan tells); the one-column kernel's are bools (map, 64-bit addressing)."""
+    EARLY form (short launches), its fourth the balanced schedule (bit-exact modes, no map; both from rmgr_ssim_hip_get_plan:
+    `plan`); the one-column kernel's are bools (map, 64-bit addressing)."""
     if mode == 2 or variant == 1:
         return "ssim_strip1_kernel<%d, %s, false>" % (mode, "true" if want_map else "false")     # last argument: 64-bit addressing (never needed by the bench's pairs)
-    return "ssim_strip2_kernel<%d, %d, %s>" % (mode, 2 if want_map else 0, "true" if early else "false")
+    balanced = bool(plan is not None and plan.balancedChunks and not want_map and mode in (0, 3))
+    early = balanced or bool(plan is not None and plan.earlyRowSums)
+    return "ssim_strip2_kernel<%d, %d, %s, %s>" % (mode, 2 if want_map else 0, "true" if early else "false", "true" if balanced else "false")
 
 
 def figures(mode, pairs, w, h, want_map, kernel_avg_ms):
@@ -290,7 +323,7 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
     batch = Batch(torch, ssim_amd, synth, ctx, dev, w, h, 0, pairs, want_map)
     sums = torch.zeros(pairs, dtype=torch.float64, device=dev)
     ctx.set_mode(mode)
-    early = bool(ssim_amd.get_plan(w, h, pairs, ctx).earlyRowSums)
+    plan = ssim_amd.get_plan(w, h, pairs, ctx)
     try:
         ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
         ctx.synchronize()
@@ -340,7 +373,7 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
     k_ms = ms / max(n, 1)
     roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
     return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
-            "kernel": kernel_name(mode, 0, want_map, early), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
+            "kernel": kernel_name(mode, 0, want_map, plan), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
             "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
             "mpix_s_wall": round(float(pairs) * w * h * steps / wall / 1e6, 1),
             "roofline": roof, "valu": valu}
@@ -481,7 +514,7 @@ def main():
     first, last = table["shards"][rank]
     mine = last - first
     batch = Batch(torch, ssim_amd, synth, ctx, dev, W, H, first, mine, want_map)
-    headline_early = bool(mine and ssim_amd.get_plan(W, H, mine, ctx).earlyRowSums)
+    headline_plan = ssim_amd.get_plan(W, H, mine, ctx) if mine else None
     sums_all = torch.zeros(total, dtype=torch.float64, device=dev)       # zero except this rank's slice
     work = torch.zeros_like(sums_all)
     my_slice_ptr = sums_all.data_ptr() + 8 * first
@@ -700,7 +733,7 @@ def main():
             roof.update({"traffic": measured_traffic(args.mode, args.workload, mine),
                          "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes committed under profiles/ (traffic.json), scaled to this batch; null if unmeasured",
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
-                         "kernel": kernel_name(args.mode, args.variant, want_map, headline_early), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
+                         "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
             valu.update({"measured_peak": VALU_MEASURED_PEAK_TOPS, "frac_of_measured_peak": round(valu["achieved"] / VALU_MEASURED_PEAK_TOPS, 4),
                          "measured_peak_at_kernel_occupancy": VALU_MEASURED_2WAVE_TOPS,
@@ -730,6 +763,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_in_child()
+            # the CPU figure of each BASELINE config beside its GPU line (all host threads, best run; the same image, the same arithmetic contract)
+            per = line["cpu_baseline"].get("per_config", {})
+            beside = {"8k-map exact": ("8k-map", "threads_all_mpix_s"), "1080p x128 exact": ("1080p-batch", "threads_all_mpix_s"),
+                      "4k double + map": ("4k-double", "with_map_threads_all_mpix_s"), "4k x1 exact": ("4k", "threads_all_mpix_s")}
+            for name, (key, field) in beside.items():
+                if name in configs and key in per and field in per[key]:
+                    configs[name]["cpu_mpix_s"] = per[key][field]
+                    configs[name]["cpu_source"] = "cpu_baseline.per_config['%s'].%s" % (key, field)
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     ctx.close()
     if dist is not None:
