@@ -412,6 +412,7 @@ def main():
                          "to see the GPUs busy (0: off; never part of `value`)")
     ap.add_argument("--watchdog", type=float, default=900.0, metavar="SECONDS", help="dump all Python stacks and exit non-zero if the run takes longer than this (0: off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the cold-start / concurrent-caller child processes of single_pair")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs after the headline")
     ap.add_argument("--print-launch", action="store_true", help="print the rank launcher command for --gpus N and exit (no GPU needed)")
     ap.add_argument("--print-shards", action="store_true", help="print the shard table (JSON: which global pairs each rank owns) for --gpus N and exit (no GPU needed)")
@@ -703,6 +704,30 @@ def main():
                   "host_pointer_call_with_map_median_ms": round(dthm_med * 1e3, 3),
                   "host_pointer_note": "unchanged rmgr_ssim_compute_ssim on pageable host memory, PCIe staging included; best and median of 6 calls"}
         del hmap, ha, hb
+        # what a one-shot caller pays (the reference's shipped callers make 1-4 calls per process), and what concurrent callers get:
+        # fresh CHILD processes (never an exec of this one), torch-free (tools/cold_start_probe.py, tools/concurrent_callers.py)
+        if not args.no_cold_start:
+            def child(*cmd):
+                try:
+                    r = subprocess.run([sys.executable] + list(cmd), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+                    return json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else {"failed": r.returncode}
+                except Exception as e:  # noqa: BLE001 -- a probe must not cost the bench its line
+                    return {"failed": repr(e)}
+            probe = os.path.join(ROOT, "tools", "cold_start_probe.py")
+            plain = [child(probe, "plain") for _ in range(2)]
+            best = min((p for p in plain if "total_ms" in p), key=lambda p: p["total_ms"], default={})
+            single["cold_first_call_ms"] = best.get("total_ms")
+            single["cold_start"] = {
+                "what": "fresh process: dlopen(librmgr-ssim-hip.so) -> first rmgr_ssim_compute_ssim() on a 1080p pair in pageable memory -> return; best of 2 processes",
+                "plain": best, "split": child(probe, "split"), "cli_bbb1080_png_vs_jpeg50": child(probe, "cli"),
+                "note": "split: runtime_init_ms = hipInit + device enumeration, context_ms = first hipSetDevice + stream (the HIP runtime's queue), "
+                        "code_object_ms = first launch of any kernel of the library = the load of its whole code object (all strip-kernel instantiations), "
+                        "first_ssim_ms vs steady_ssim_ms = first launch of the strip kernel + reduction"}
+            single["concurrent_callers"] = child(os.path.join(ROOT, "tools", "concurrent_callers.py"), "4096", "1", "1,2,4", "1.0", "--json")
+            single["concurrent_callers_1080p"] = child(os.path.join(ROOT, "tools", "concurrent_callers.py"), "1920", "1", "1,2,4", "1.0", "--json")
+            single["concurrent_callers_note"] = ("N host threads looping the unchanged rmgr_ssim_compute_ssim WITH the map on pageable memory, each call on a leased default "
+                                                 "context; 4096^2 + map moves 33.5 MB in and 67 MB out per call: at the ~56 GB/s a pageable copy attains on this link one "
+                                                 "direction alone caps the call rate near 14 k Mpix/s, so one thread already sits at ~75 % of it")
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)      # restore the slice for consistency
         torch.cuda.synchronize()
 

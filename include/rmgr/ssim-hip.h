@@ -59,6 +59,10 @@ extern "C" {
 #define RMGR_SSIM_HIP_ABI_VERSION 4
 rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT;
 
+/* The default contexts of the ctx == NULL entry points (see rmgr_ssim_hip_compute_ssim_host): how many exist right now and how many
+ * calls may be in flight at a time.  Either pointer may be NULL.  Creates nothing. */
+rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT;
+
 /* An engine instance: one device, one stream, its own grow-only scratch.  A context may be used by one
  * host thread at a time (create one per thread, or serialise); the NULL / default context of the
  * host-pointer entry points is shared process-wide and locked internally. */
@@ -111,8 +115,12 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint3
 /*
  * compute_ssim() on HOST pointers: stages both images to HBM, runs the kernels, copies the map
  * back (any ssimStep/ssimStride), returns the global SSIM.  Validation and return codes are the
- * reference's (src/ssim.cpp:962-978).  ctx may be NULL: a process-wide default context on
- * device 0 (or $RMGR_SSIM_HIP_DEVICE) is used under a lock.
+ * reference's (src/ssim.cpp:962-978).  ctx may be NULL: the call then runs on one of the process-wide DEFAULT contexts
+ * on device 0 (or $RMGR_SSIM_HIP_DEVICE), leased for the duration of the call.  Like the reference's function
+ * (re-entrant, no global state: src/ssim.cpp:933-1106) concurrent callers run side by side -- each on a context of its
+ * own (stream, staging buffers, pinned memory), one caller's copy-in under another's kernel and a third's map on its way
+ * back -- up to $RMGR_SSIM_HIP_POOL calls at a time (default 4; 1 serialises them as rounds 1-4 did); further callers
+ * wait for a lease.  Contexts are created on demand: a single-threaded process has one.
  * A large pair with a map is processed in row bands -- copy-in of band k+1, kernel on band k and the copy-back of
  * band k-1's map rows (by a short-lived helper thread, straight into ssimMap) overlap; the results are bit-identical
  * to the one-launch computation.  $RMGR_SSIM_HIP_BANDS overrides the band count (1: no overlap) and sends a large pair through

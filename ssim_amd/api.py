@@ -76,7 +76,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
     "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
-    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version",
+    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool",
     "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
@@ -230,6 +230,15 @@ def compute_ssim(a, b, want_map=False, openmp=False, allocator=False, out_map=No
     else:
         _check("rmgr_ssim_compute_ssim", lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None))
     return np.float32(out.value), m
+
+
+def default_pool():
+    """(contexts that exist, calls that may be in flight at a time) of the ctx == NULL entry points' default contexts."""
+    lib = load_library()
+    n, lim = ctypes.c_int32(), ctypes.c_int32()
+    lib.rmgr_ssim_hip_get_default_pool.argtypes = [ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+    _check("rmgr_ssim_hip_get_default_pool", lib.rmgr_ssim_hip_get_default_pool(ctypes.byref(n), ctypes.byref(lim)))
+    return n.value, lim.value
 
 
 def compute_ssim_batch(pairs, ctx=None):

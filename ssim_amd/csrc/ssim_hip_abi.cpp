@@ -491,27 +491,98 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
 
 int comm_bounded_sync(rmgr_ssim_hip_Context* c);      // with the RCCL section below
 
-rmgr_ssim_hip_Context* g_default = NULL;
-int                    g_default_err = 0;
-std::once_flag         g_default_once;
+// ---- the process-wide default contexts of the drop-in entry points (ctx == NULL) -------------------------------------
+// The reference's compute_ssim() is re-entrant and has no global state (src/ssim.cpp:933-1106): six caller threads get six
+// computations running side by side.  Rounds 1-4 ran every ctx == NULL call on ONE default context under its lock: six
+// serialised copy-in -> kernel -> copy-out sequences.  Now the default is a small POOL of contexts on the default device
+// ($RMGR_SSIM_HIP_DEVICE), each with its own stream, staging buffers and pinned memory: a call leases one for its duration,
+// so that one caller's copy-in runs under another's kernel and a third's map on its way back.  Contexts are created on
+// demand -- a single-threaded process only ever has one -- up to $RMGR_SSIM_HIP_POOL (default 4, 1 = the old behaviour);
+// callers beyond that wait for a lease.  The arithmetic mode of the drop-in calls (rmgr_ssim_hip_set_mode(NULL, ...), i.e.
+// rmgr::ssim::select_impl, $RMGR_SSIM_HIP_MODE, the double build's default) is a property of the pool, applied at lease time.
+struct DefaultPool {
+    std::mutex m;
+    std::condition_variable freed;
+    std::vector<rmgr_ssim_hip_Context*> all, idle;
+    int device, limit, mode, create_err;
+    bool configured;
+    DefaultPool() : device(0), limit(4), mode(RMGR_SSIM_HIP_MODE_EXACT), create_err(0), configured(false) {}
+};
+DefaultPool g_pool;       // never destroyed contexts: the process may still be inside a call at exit (as before)
 
-rmgr_ssim_hip_Context* default_context(int* err)
+void pool_configure_locked()
 {
-    std::call_once(g_default_once, []() {
-        int dev = 0;
-        if (const char* s = getenv("RMGR_SSIM_HIP_DEVICE")) dev = atoi(s);
-        g_default_err = rmgr_ssim_hip_create(&g_default, dev, NULL);
-        if (g_default && g_default_err == 0) {
-            const char* m = getenv("RMGR_SSIM_HIP_MODE");
-            if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_SEPARABLE) g_default->mode = atoi(m);
+    if (g_pool.configured) return;
+    g_pool.configured = true;
+    if (const char* s = getenv("RMGR_SSIM_HIP_DEVICE")) g_pool.device = atoi(s);
+    if (const char* s = getenv("RMGR_SSIM_HIP_POOL")) { const int n = atoi(s); if (n >= 1 && n <= 64) g_pool.limit = n; }
+    const char* m = getenv("RMGR_SSIM_HIP_MODE");
+    if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_SEPARABLE) g_pool.mode = atoi(m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
-            else g_default->mode = RMGR_SSIM_HIP_MODE_DOUBLE;
+    else g_pool.mode = RMGR_SSIM_HIP_MODE_DOUBLE;
 #endif
-        }
-    });
-    *err = g_default_err;
-    return g_default;
 }
+
+// A context of the pool for the duration of one call; blocks while `limit` calls are in flight.
+int pool_acquire(rmgr_ssim_hip_Context** out)
+{
+    std::unique_lock<std::mutex> lk(g_pool.m);
+    pool_configure_locked();
+    for (;;) {
+        if (!g_pool.idle.empty()) {
+            *out = g_pool.idle.back();
+            g_pool.idle.pop_back();
+            (*out)->mode = g_pool.mode;
+            return 0;
+        }
+        if (g_pool.create_err && g_pool.all.empty()) return g_pool.create_err;      // no device: every call fails the same way, at once
+        if ((int)g_pool.all.size() < g_pool.limit) {
+            g_pool.all.push_back(NULL);                                             // reserve a slot; create outside the lock
+            lk.unlock();
+            rmgr_ssim_hip_Context* c = NULL;
+            const int rc = rmgr_ssim_hip_create(&c, g_pool.device, NULL);
+            lk.lock();
+            if (rc || !c) {
+                g_pool.all.erase(std::find(g_pool.all.begin(), g_pool.all.end(), (rmgr_ssim_hip_Context*)NULL));      // one reserved slot (any: they are alike)
+                g_pool.create_err = rc ? rc : ENODEV;
+                g_pool.freed.notify_all();
+                if (g_pool.all.empty()) return g_pool.create_err;
+                continue;                                                           // others exist: wait for one of them
+            }
+            *std::find(g_pool.all.begin(), g_pool.all.end(), (rmgr_ssim_hip_Context*)NULL) = c;
+            c->mode = g_pool.mode;
+            *out = c;
+            return 0;
+        }
+        g_pool.freed.wait(lk);
+    }
+}
+
+void pool_release(rmgr_ssim_hip_Context* c)
+{
+    { std::lock_guard<std::mutex> lk(g_pool.m); g_pool.idle.push_back(c); }
+    g_pool.freed.notify_one();
+}
+
+// The context a call runs on: the caller's, or a leased default one (returned when the call ends).
+struct Lease {
+    rmgr_ssim_hip_Context* c;
+    bool pooled;
+    Lease() : c(NULL), pooled(false) {}
+    int take(rmgr_ssim_hip_Context* given)
+    {
+        if (given) { c = given; return 0; }
+        const int rc = pool_acquire(&c);
+        if (rc) { c = NULL; return rc; }
+        if (!c) return ENODEV;
+        pooled = true;
+        return 0;
+    }
+    ~Lease() { if (pooled && c) pool_release(c); }
+private:
+    Lease(const Lease&);
+    Lease& operator=(const Lease&);
+};
 
 } // namespace
 
@@ -620,16 +691,16 @@ rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode)
 {
     if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_SEPARABLE) return EINVAL;
     if (!c) {
-        // the process-wide default context of the drop-in entry points (what rmgr::ssim::select_impl switches)
-        int rc = 0;
-        c = default_context(&rc);
+        // the process-wide default contexts of the drop-in entry points (what rmgr::ssim::select_impl switches): a property of the
+        // pool, applied to a context when a call leases it.  As before the call needs a device (ENODEV without one).
+        Lease probe;
+        const int rc = probe.take(NULL);
         if (rc) return rc;
-        if (!c) return ENODEV;
-        std::lock_guard<std::mutex> guard(c->lock);
+        std::lock_guard<std::mutex> guard(g_pool.m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
         if (mode == RMGR_SSIM_HIP_MODE_EXACT || mode == RMGR_SSIM_HIP_MODE_UNFUSED) mode = RMGR_SSIM_HIP_MODE_DOUBLE;   // a double build stays double
 #endif
-        c->mode = mode;
+        g_pool.mode = mode;
         return 0;
     }
     c->mode = mode;
@@ -639,13 +710,12 @@ rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode)
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* c, rmgr_int32_t* mode) RMGR_NOEXCEPT
 {
     if (!mode) return EINVAL;
-    if (!c) {                 // the process-wide default context, as for set_mode (created on first use; ENODEV without a device)
-        int rc = 0;
-        rmgr_ssim_hip_Context* d = default_context(&rc);
+    if (!c) {                 // the process-wide default contexts, as for set_mode (created on first use; ENODEV without a device)
+        Lease probe;
+        const int rc = probe.take(NULL);
         if (rc) return rc;
-        if (!d) return ENODEV;
-        std::lock_guard<std::mutex> guard(d->lock);
-        *mode = d->mode;
+        std::lock_guard<std::mutex> guard(g_pool.m);
+        *mode = g_pool.mode;
         return 0;
     }
     *mode = c->mode;
@@ -657,6 +727,18 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t str
     if (!c || stripRows < 0 || variant < 0) return EINVAL;
     c->strip_rows = stripRows;
     c->variant = variant;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT
+{
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    pool_configure_locked();
+    if (contexts) {
+        *contexts = 0;
+        for (size_t i = 0; i < g_pool.all.size(); ++i) *contexts += g_pool.all[i] != NULL;
+    }
+    if (limit) *limit = g_pool.limit;
     return 0;
 }
 
@@ -754,13 +836,9 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_batch_host(rmgr_ssim_hip_Context* c, rmg
         if (params[i].width != params[0].width || params[i].height != params[0].height) return EINVAL;
     }
     int rc = 0;
-    std::unique_lock<std::mutex> guard;
-    if (!c) {
-        c = default_context(&rc);
-        if (rc) return rc;
-        if (!c) return ENODEV;
-        guard = std::unique_lock<std::mutex>(c->lock);
-    }
+    Lease lease;
+    if ((rc = lease.take(c))) return rc;
+    c = lease.c;
     USE_DEVICE(c);
     const uint32_t W = params[0].width, H = params[0].height;
     if (W == 0 || H == 0) {                       // 0/0, like the single call
@@ -874,13 +952,9 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
 {
     int rc = validate(ssim, params, threadPool);
     if (rc) return rc;
-    std::unique_lock<std::mutex> guard;
-    if (!c) {
-        c = default_context(&rc);
-        if (rc) return rc;
-        if (!c) return ENODEV;
-        guard = std::unique_lock<std::mutex>(c->lock);
-    }
+    Lease lease;                         // ctx == NULL: one of the default contexts, for this call only (concurrent callers overlap)
+    if ((rc = lease.take(c))) return rc;
+    c = lease.c;
     USE_DEVICE(c);
     const uint32_t W = params->width, H = params->height;
 
@@ -1052,7 +1126,7 @@ namespace {
 
 struct StagedPair {
     rmgr_ssim_hip_Context* c;
-    std::unique_lock<std::mutex> guard;
+    Lease lease;
     DeviceGuard device;           // the context's device stays current for as long as the staged pair lives, i.e. for the WHOLE
                                   // entry point: its later allocations, events and launches must not land on the caller's device
     uint8_t* a; uint8_t* b;       // device copies of the two interleaved images, rows `pitch` bytes apart
@@ -1066,12 +1140,8 @@ int stage_interleaved(rmgr_ssim_hip_Context* c, StagedPair& sp, const void* out1
 {
     if ((out1 == NULL && out2 == NULL) || imgA == NULL || imgB == NULL || channels == 0) return EINVAL;
     int rc = 0;
-    if (!c) {
-        c = default_context(&rc);
-        if (rc) return rc;
-        if (!c) return ENODEV;
-        sp.guard = std::unique_lock<std::mutex>(c->lock);
-    }
+    if ((rc = sp.lease.take(c))) return rc;
+    c = sp.lease.c;
     sp.c = c;
     if ((rc = sp.device.enter(c->device))) return rc;
     sp.pitch = ((size_t)width * channels + 3) & ~(size_t)3;      // dword-aligned rows for the packed luminance path

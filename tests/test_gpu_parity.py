@@ -498,15 +498,19 @@ def test_reference_test_matrix_on_host_entry_points(manifest, refsets, openmp, h
 
 
 def test_dropin_call_is_thread_safe(manifest):
-    """The reference's compute_ssim is re-entrant (SURVEY.md 8(b) "Threading"); the drop-in call shares one
-    default context under a lock.  Hammer it from several host threads with different inputs."""
+    """The reference's compute_ssim is re-entrant and parallel across callers (SURVEY.md 8(b) "Threading"; src/ssim.cpp:933-1106 has no
+    global state).  The drop-in call leases one of the process-wide default contexts per call (round 5; rounds 1-4: one context under a
+    lock).  Hammer it from several host threads with different inputs, with and without the map: every result bit-exact, and the pool
+    must have grown beyond one context but not beyond its limit -- six threads, four leases."""
     import threading
     names = [n for n in image_entries(manifest)][:8]
     pairs = [(load_pair(manifest[n]), manifest[n]["fma"]["ssim_hex"], manifest[n]["fma"]["map_sha256"]) for n in names]
     errors = []
+    gate = threading.Barrier(6)
 
     def work(tid):
         try:
+            gate.wait()
             for it in range(12):
                 (a, b), want, want_map = pairs[(tid + it) % len(pairs)]
                 v, m = ssim_amd.compute_ssim(a, b, want_map=(it % 2 == 0))
@@ -520,6 +524,35 @@ def test_dropin_call_is_thread_safe(manifest):
     for t in threads:
         t.join()
     assert not errors, errors
+    contexts, limit = ssim_amd.default_pool()
+    assert limit == int(os.environ.get("RMGR_SSIM_HIP_POOL", "4")) and 1 <= contexts <= limit
+    assert contexts >= 2 or limit == 1, "six concurrent callers were served by a single default context"
+
+
+def test_default_pool_follows_the_mode_of_the_drop_in_calls(manifest):
+    """rmgr_ssim_hip_set_mode(NULL, ...) -- what rmgr::ssim::select_impl drives -- is a property of the pool: every default context, the
+    ones that exist and the ones concurrent callers create later, computes in that mode."""
+    import threading
+    lib = ssim_amd.load_library()
+    ent = manifest["einstein_blur"]
+    a, b = load_pair(ent)
+    assert lib.rmgr_ssim_hip_set_mode(None, ssim_amd.MODE_UNFUSED) == 0
+    try:
+        got = []
+        gate = threading.Barrier(5)
+
+        def work():
+            gate.wait()
+            got.append(f32_hex(ssim_amd.compute_ssim(a, b)[0]))
+        threads = [threading.Thread(target=work) for _ in range(5)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert got == [ent["avx"]["ssim_hex"]] * 5, got
+    finally:
+        assert lib.rmgr_ssim_hip_set_mode(None, ssim_amd.MODE_EXACT) == 0
+    assert f32_hex(ssim_amd.compute_ssim(a, b)[0]) == ent["fma"]["ssim_hex"]
 
 
 def test_two_contexts_and_mode_switching(gpu_ctx, manifest):
