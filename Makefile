@@ -46,9 +46,11 @@ $(OBJ)/ssim_openmp_marker.o: $(SRC)/ssim_openmp_marker.c
 	@mkdir -p $(OBJ)
 	$(CC) -std=c89 -pedantic -O2 -fPIC -Wall -Iinclude -c $< -o $@
 
+# The kernels carry the sha256 of their own source (rmgr_ssim_hip_get_kernel_source_id): measurements that belong to one version of
+# the kernels -- profiles/traffic.json -- name it, and bench.py refuses to quote them for any other.
 $(OBJ)/ssim_kernels.o: $(SRC)/ssim_kernels.hip $(SRC)/ssim_kernels.h
 	@mkdir -p $(OBJ)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -DSSIM_KERNELS_SOURCE_ID=\"$$(sha256sum $< | cut -c1-64)\" -c $< -o $@
 
 $(OBJ)/ssim_hip_abi.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h include/rmgr/ssim-hip.h include/rmgr/ssim.h
 	@mkdir -p $(OBJ)

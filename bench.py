@@ -232,19 +232,27 @@ def cpu_baseline(budget_s=10.0):
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
-def measured_traffic(mode, workload, pairs):
-    """HBM bytes per launch from the committed PMC measurement (profiles/traffic.json: rocprofv3 --pmc passes of
-    tools/profile_target.py, FETCH_SIZE/WRITE_SIZE corrected per profiles/r01_fetch_size_calibration.md), scaled
-    from the measured batch to this one; None when no measurement exists for the configuration."""
+def measured_traffic(mode, workload, pairs, kernel_id):
+    """(HBM bytes per launch, note) from the committed PMC measurement (profiles/traffic.json: rocprofv3 --pmc passes of
+    tools/profile_target.py, FETCH_SIZE/WRITE_SIZE corrected per profiles/r01_fetch_size_calibration.md).  The file names the kernel
+    source it was collected from (sha256 of ssim_kernels.hip); the RUNNING library reports the source it was compiled from
+    (rmgr_ssim_hip_get_kernel_source_id): for any other kernel version the figure is None -- a measurement of other code is not
+    this run's traffic.  The headline batch (32 x 4096^2) is measured as such, nothing is scaled; other batch sizes scale per pair."""
     key = {"4k": "exact_4096_nomap", "8k-map": "exact_8192_map", "1080p": "exact_1080p_nomap"}.get(workload)
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        if mode == 0 and key in t:
-            return float(t[key]["bytes_per_pair"]) * pairs
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+    except (OSError, ValueError):
+        return None, "profiles/traffic.json missing or unreadable"
+    if mode != 0 or key not in t:
+        return None, "no PMC measurement of this configuration in profiles/traffic.json"
+    if t.get("kernel_source_sha256") != kernel_id:
+        return None, ("profiles/traffic.json was collected from kernel source %s..., the running library was compiled from %s...: not quoted (re-run "
+                      "tools/collect_profiles.sh + tools/publish_profiles.sh)" % (str(t.get("kernel_source_sha256"))[:12], kernel_id[:12]))
+    e = t[key]
+    how = "measured on this very batch" if int(e["pairs"]) == pairs else "measured on %d pairs, scaled per pair to %d" % (e["pairs"], pairs)
+    return float(e["bytes_per_pair"]) * pairs, ("HBM bytes per launch from rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections) of the same kernel "
+                                                "source (sha256 %s...), committed as profiles/traffic.json; %s" % (kernel_id[:12], how))
 
 
 def attainable_hbm_gbs(torch, dev):
@@ -706,7 +714,7 @@ def main():
         del hmap, ha, hb
         # what a one-shot caller pays (the reference's shipped callers make 1-4 calls per process), and what concurrent callers get:
         # fresh CHILD processes (never an exec of this one), torch-free (tools/cold_start_probe.py, tools/concurrent_callers.py)
-        if not args.no_cold_start:
+        if not args.no_cold_start and world == 1:
             def child(*cmd):
                 try:
                     r = subprocess.run([sys.executable] + list(cmd), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
@@ -755,8 +763,8 @@ def main():
         value = pixels / elapsed / 1e6
         roof, valu = figures(args.mode, mine, W, H, want_map, kernel_avg_ms) if mine else ({}, {})
         if roof:
-            roof.update({"traffic": measured_traffic(args.mode, args.workload, mine),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 --pmc passes committed under profiles/ (traffic.json), scaled to this batch; null if unmeasured",
+            traffic, traffic_note = measured_traffic(args.mode, args.workload, mine, ssim_amd.kernel_source_id())
+            roof.update({"traffic": traffic, "traffic_note": traffic_note,
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
                          "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})

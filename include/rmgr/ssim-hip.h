@@ -59,6 +59,10 @@ extern "C" {
 #define RMGR_SSIM_HIP_ABI_VERSION 4
 rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT;
 
+/* sha256 (hex) of the kernel source this library's device code was compiled from ("unknown" when it was not built by the Makefile).
+ * Measurements tied to one version of the kernels -- profiles/traffic.json -- record it, and bench.py quotes them only for that version. */
+const char* rmgr_ssim_hip_get_kernel_source_id(void) RMGR_NOEXCEPT;
+
 /* The default contexts of the ctx == NULL entry points (see rmgr_ssim_hip_compute_ssim_host): how many exist right now and how many
  * calls may be in flight at a time.  Either pointer may be NULL.  Creates nothing. */
 rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT;

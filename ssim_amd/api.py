@@ -76,7 +76,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_compute_ssim_channels_host", "rmgr_ssim_hip_compute_ssim_luminance_host", "rmgr_ssim_hip_luminance_device",
     "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
-    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool",
+    "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool", "rmgr_ssim_hip_get_kernel_source_id",
     "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
@@ -230,6 +230,14 @@ def compute_ssim(a, b, want_map=False, openmp=False, allocator=False, out_map=No
     else:
         _check("rmgr_ssim_compute_ssim", lib.rmgr_ssim_compute_ssim(ctypes.byref(out), ctypes.byref(p), None))
     return np.float32(out.value), m
+
+
+def kernel_source_id():
+    """sha256 of the kernel source the loaded library was compiled from (rmgr_ssim_hip_get_kernel_source_id)."""
+    lib = load_library()
+    lib.rmgr_ssim_hip_get_kernel_source_id.restype = ctypes.c_char_p
+    lib.rmgr_ssim_hip_get_kernel_source_id.argtypes = []
+    return lib.rmgr_ssim_hip_get_kernel_source_id().decode()
 
 
 def default_pool():

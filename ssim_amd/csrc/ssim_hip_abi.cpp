@@ -730,6 +730,11 @@ rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* c, rmgr_int32_t str
     return 0;
 }
 
+const char* rmgr_ssim_hip_get_kernel_source_id(void) RMGR_NOEXCEPT
+{
+    return ssim_hip::kernels_source_id();
+}
+
 rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT
 {
     std::lock_guard<std::mutex> lk(g_pool.m);

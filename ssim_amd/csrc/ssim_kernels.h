@@ -131,6 +131,9 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
 size_t reduce_scratch_size(const Geometry& geo);
 hipError_t launch_reduce(const Geometry& geo, const double* partials, double* chunk_sums, double* sums, hipStream_t stream);
 
+// sha256 of ssim_kernels.hip as it was compiled (the Makefile passes it in; "unknown" for any other build).
+const char* kernels_source_id();
+
 // BT.601 luminance of interleaved pixels (src/ssim-cli.cpp:158-186), device to device.
 hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src, int64_t src_step, int64_t src_stride,
                             uint32_t width, uint32_t height, hipStream_t stream);

@@ -1447,6 +1447,11 @@ hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b
     return hipGetLastError();
 }
 
+#ifndef SSIM_KERNELS_SOURCE_ID
+#define SSIM_KERNELS_SOURCE_ID "unknown"
+#endif
+const char* kernels_source_id() { return SSIM_KERNELS_SOURCE_ID; }
+
 // Waves per SIMD each kernel runs at (its VGPR count): what plan() packs strips with.
 static int waves_per_simd(int mode, int variant)
 {

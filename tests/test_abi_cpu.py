@@ -269,6 +269,31 @@ def test_select_impl_reports_nothing_without_a_device(lib):
 
 
 @pytest.mark.skipif(has_gpu(), reason="checks the no-device behaviour")
+def test_bench_quotes_pmc_traffic_only_for_the_kernels_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed PMC measurement (profiles/traffic.json).  The file names the sha256 of
+    the ssim_kernels.hip it was collected from, the library reports the source it was compiled from
+    (rmgr_ssim_hip_get_kernel_source_id): any mismatch -> null with a note, never another kernel's bytes."""
+    import hashlib
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    kid = ssim_amd.kernel_source_id()
+    src = os.path.join(ROOT, "ssim_amd", "csrc", "ssim_kernels.hip")
+    assert kid == hashlib.sha256(open(src, "rb").read()).hexdigest(), "the library in ssim_amd/lib was not built from the kernel source in the tree (make lib)"
+    fake = {"kernel_source_sha256": kid, "exact_4096_nomap": {"pairs": 32, "bytes_per_pair": 34000000.0}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "traffic.json").write_text(json.dumps(fake))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    v, note = bench.measured_traffic(0, "4k", 32, kid)
+    assert v == 32 * 34000000.0 and "this very batch" in note
+    v, note = bench.measured_traffic(0, "4k", 8, kid)
+    assert v == 8 * 34000000.0 and "scaled per pair" in note
+    v, note = bench.measured_traffic(0, "4k", 32, "0" * 64)               # another kernel version
+    assert v is None and "not quoted" in note
+    assert bench.measured_traffic(4, "4k", 32, kid)[0] is None           # another arithmetic mode: never measured
+    assert bench.measured_traffic(0, "8k-map", 2, kid)[0] is None        # a configuration the file does not hold
+
+
 def test_bench_refuses_to_run_without_the_gpu():
     """bench.py measures the HIP path or nothing: no device -> a loud non-zero exit, never a CPU number."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)

@@ -10,13 +10,13 @@ for wl in 4k 8k-map 1080p; do
   timeout 600 python3 bench.py --workload $wl > "$OUT/bench_$wl.log" 2>&1
   grep '"metric"' "$OUT/bench_$wl.log" > "$OUT/bench_$wl.json"
 done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --no-cpu-baseline --sustain 0 > "$OUT/bench_under_rocprof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o t -- python3 bench.py --no-cpu-baseline --no-cold-start --sustain 0 > "$OUT/bench_under_rocprof.log" 2>&1
 # the exchange step on a 1-rank communicator: the product's own carrier (--exchange native), torch's, and configs[3] whole
-SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-configs --sustain 0 --exchange native > "$OUT/bench_rccl_1rank.log" 2>&1
+SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-cold-start --no-configs --sustain 0 --exchange native > "$OUT/bench_rccl_1rank.log" 2>&1
 grep '"metric"' "$OUT/bench_rccl_1rank.log" > "$OUT/bench_rccl_1rank.json"
-SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-configs --sustain 0 --exchange torch > "$OUT/bench_rccl_1rank_torch.log" 2>&1
+SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-cold-start --no-configs --sustain 0 --exchange torch > "$OUT/bench_rccl_1rank_torch.log" 2>&1
 grep '"metric"' "$OUT/bench_rccl_1rank_torch.log" > "$OUT/bench_rccl_1rank_torch.json"
-SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-configs --sustain 0 --workload 1080p --scaling strong > "$OUT/bench_c4_strong.log" 2>&1
+SSIM_BENCH_FORCE_DIST=1 timeout 600 python3 bench.py --no-cpu-baseline --no-cold-start --no-configs --sustain 0 --workload 1080p --scaling strong > "$OUT/bench_c4_strong.log" 2>&1
 grep '"metric"' "$OUT/bench_c4_strong.log" > "$OUT/bench_c4_strong.json"
 for m in single absent-peer shards; do RMGR_SSIM_HIP_COMM_TIMEOUT_S=10 timeout 100 python3 tools/rccl_selftest.py $m 2>&1 | grep "rccl_selftest\|rmgr-ssim comm"; done > "$OUT/rccl_selftest.txt"
 timeout 150 python3 tools/rccl_selftest.py single --with-torch 2>&1 | grep "rccl_selftest\|rmgr-ssim comm" >> "$OUT/rccl_selftest.txt"
@@ -27,7 +27,7 @@ pmc() {   # name, counters, target args...
   local name=$1 ctrs=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
 }
-for cfg in "4k 8 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
+for cfg in "4k 32 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
   set -- $cfg; tag=$1; shift
   pmc ${tag}_fetch FETCH_SIZE "$@"
   pmc ${tag}_write WRITE_SIZE "$@"
