@@ -570,6 +570,24 @@ def main():
         if abs(mm - float(res[first])) > 1e-6:
             raise SystemExit("map mean %.9f disagrees with the global SSIM" % mm)
     result_digest = "%016x" % (int(np.bitwise_xor.reduce(res.view(np.uint32).astype(np.uint64) * (np.arange(res.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1)))) & 0xFFFFFFFFFFFFFFFF)
+    # --- self-diagnosis of a multi-rank run, BEFORE anything is timed: every rank says which device it bound (index + PCI bus id), which
+    #     carrier the exchange uses and how many ranks RCCL counts, and the digest of the result vector it holds after the exchange.  The
+    #     all-reduce gives every rank every sum: a rank whose digest differs from rank 0's computed something else, and the run aborts
+    #     non-zero instead of printing a number (the first N > 1 run on hardware is the driver's: it must explain itself) ---
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+    except Exception:  # noqa: BLE001
+        pci = "unknown"
+    who = "device %d (pci %s, %s) pairs [%d, %d) carrier %s ranks_seen %s" % (local_rank, pci, torch.cuda.get_device_name(dev), first, last, exchange["carrier"], exchange["ranks_seen"])
+    digests_ok, rank_lines = sharding.compare_digests(dist, result_digest, who)
+    if rank == 0 and (world > 1 or not digests_ok):
+        for l in rank_lines:
+            sys.stderr.write("bench.py: %s\n" % l)
+        sys.stderr.flush()
+    if not digests_ok:
+        raise SystemExit("bench.py: the ranks hold different result vectors after the exchange (see the per-rank lines above): no number is reported")
+    exchange["per_rank"] = rank_lines
 
     # Clock settle (untimed, before the W warm-up steps): the chip takes tens of milliseconds of sustained load
     # to leave its idle DVFS state; a ~1 ms step measured right after the uploads reads up to 20 % slow.

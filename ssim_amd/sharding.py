@@ -88,3 +88,18 @@ def exchange_sums_native(ctx, sums_all, work):
     work.copy_(sums_all)
     ctx.comm_allreduce_sums(work.data_ptr(), work.numel())
     return work
+
+
+def compare_digests(dist, digest, describe=""):
+    """Every rank contributes the digest of the result vector IT holds after the exchange (and a line describing itself);
+    returns (ok, lines) on every rank: ok iff all digests equal rank 0's, lines = one "rank r: <describe> digest <d>" per rank.
+    The all-reduce gives every rank every sum, so the digests must agree; a rank that disagrees computed something else
+    (wrong device, missed exchange, a communicator that did not span the launch) and the run must not produce a number."""
+    if dist is None or not dist.is_initialized():
+        return True, ["rank 0: %s digest %s" % (describe, digest)]
+    world = dist.get_world_size()
+    box = [None] * world
+    dist.all_gather_object(box, (dist.get_rank(), describe, digest))
+    box.sort()
+    lines = ["rank %d: %s digest %s%s" % (r, d, g, "" if g == box[0][2] else "   <-- differs from rank 0") for r, d, g in box]
+    return all(g == box[0][2] for _, _, g in box), lines

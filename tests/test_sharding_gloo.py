@@ -120,6 +120,46 @@ def test_native_exchange_id_handoff_and_agreement(tmp_path, fail):
     assert got[0][1] == got[1][1] == ("1" if fail == "" else "0")       # native only if EVERY rank is up
 
 
+def digest_worker(rank, world, port, out_dir, corrupt):
+    """bench.py's self-diagnosis before timing: every rank's digest of the vector it holds after the exchange, compared on all
+    ranks.  corrupt: rank 1 holds a vector that differs in one bit (a rank that missed the exchange / ran on the wrong data)."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from ssim_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = sharding.shard_range(rank, world, PAIRS_PER_RANK)
+    sums_all = torch.zeros(world * PAIRS_PER_RANK, dtype=torch.float64)
+    for i in range(first, last):
+        sums_all[i] = image_sum(i)
+    full = sharding.exchange_sums(sums_all, torch.zeros_like(sums_all), dist).numpy().copy()
+    if corrupt and rank == 1:
+        full.view(np.uint64)[2] ^= 1
+    digest = "%016x" % int(np.bitwise_xor.reduce(full.view(np.uint64) * (np.arange(full.size, dtype=np.uint64) * np.uint64(2) + np.uint64(1))))
+    ok, lines = sharding.compare_digests(dist, digest, "device %d carrier torch ranks_seen %d" % (rank, world))
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("%d\n%s\n" % (int(ok), "\n".join(lines)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt", [False, True])
+def test_ranks_compare_result_digests_before_timing(tmp_path, corrupt):
+    """a multi-rank bench run must diagnose itself -- the same verdict and the same per-rank lines on every rank,
+    agreement when the exchange worked, a flagged rank (and hence a non-zero exit in bench.py) when one rank holds other bits."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = 35500 + (os.getpid() % 2000) + int(corrupt)
+    mp.spawn(digest_worker, args=(world, port, str(tmp_path), corrupt), nprocs=world, join=True)
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().strip().split("\n") for r in range(world)]
+    assert got[0] == got[1]                                     # every rank sees the same verdict and the same lines
+    assert got[0][0] == ("0" if corrupt else "1")
+    assert len(got[0]) == 1 + world and got[0][1].startswith("rank 0: device 0 carrier torch ranks_seen 2 digest ")
+    assert ("differs from rank 0" in got[0][2]) == corrupt
+
+
 def test_bench_builds_its_own_rank_launcher():
     """`python bench.py --gpus N` must not depend on an outside launcher: it starts
     torch.distributed.run itself, as a child process, on 127.0.0.1."""
