@@ -238,9 +238,15 @@ rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uin
  *
  * Bounded failure.  Where the reference reports a failed worker as ECHILD (src/ssim.cpp:1094-1097), a rank that never
  * arrives is reported here as ETIMEDOUT after $RMGR_SSIM_HIP_COMM_TIMEOUT_S seconds (default 30): get_unique_id and
- * comm_init (library load, bootstrap, rendezvous), the enqueue inside comm_allreduce_sums, rmgr_ssim_hip_synchronize()
- * on a context that owns a communicator (the queued collective's peers may never launch theirs), and comm_destroy all
- * return by that deadline.  After ETIMEDOUT the context is back in its single-GPU state -- it still computes, and
+ * comm_init (library load, bootstrap, rendezvous), the enqueue inside comm_allreduce_sums, and every wait for a QUEUED
+ * all-reduce -- rmgr_ssim_hip_synchronize(), comm_destroy and rmgr_ssim_hip_destroy on a context with all-reduces outstanding --
+ * are bounded by it.  The deadline of a queued all-reduce runs from the moment its turn on the stream has come, not from the call:
+ * kernels queued before or after it may take as long as they take (each all-reduce sits between two events; the wait polls them,
+ * sleeping 50 us ... 1 ms between polls).  Past the deadline the communicator is aborted (ncclCommAbort), which releases the
+ * kernel that waits for the missing peers; the wait for that kernel to leave is bounded by one more such interval.  A library
+ * without ncclCommAbort cannot release it: ETIMEDOUT is returned and the stream is left as it is.  ncclCommDestroy of a BLOCKING
+ * communicator ($RMGR_SSIM_HIP_COMM_BLOCKING=1) waits for the peers inside RCCL and is not bounded; the default (non-blocking)
+ * communicator's teardown is.  After ETIMEDOUT the context is back in its single-GPU state -- it still computes, and
  * comm_init may be called again (tests/test_gpu_zz_rccl.py does both).  How: library load, ncclGetUniqueId and the
  * communicator's creation run on a helper thread the caller waits for with a timeout; the communicator is requested
  * non-blocking (ncclCommInitRankConfig, blocking = 0) and, if the deadline passes while its rendezvous is in progress,

@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <deque>
 #include <vector>
 
 using ssim_hip::PairDesc;
@@ -74,6 +75,12 @@ struct rmgr_ssim_hip_Context_ {
     double   prof_ms;
 
     ncclComm_t comm;          // RCCL communicator (rmgr_ssim_hip_comm_*), NULL until comm_init
+    // every queued all-reduce is bracketed by two events on the stream: what is still outstanding, oldest first.  The deadline of
+    // rmgr_ssim_hip_synchronize / _destroy applies to ONE collective from the moment its turn has come (its `begin` event is complete) --
+    // never to the kernels queued around it (30 s of legitimate work used to get a healthy communicator aborted)
+    struct Collective { hipEvent_t begin, end; bool started; std::chrono::steady_clock::time_point since; };
+    std::deque<Collective> collectives;
+    std::vector<hipEvent_t> spare_events;
     bool       comm_nonblocking;   // created with ncclCommInitRankConfig(blocking = 0): calls may report "in progress"
     int        comm_ranks;         // ncclCommCount of the communicator
 
@@ -490,6 +497,7 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
 }
 
 int comm_bounded_sync(rmgr_ssim_hip_Context* c);      // with the RCCL section below
+void comm_forget_collectives(rmgr_ssim_hip_Context* c);
 
 // ---- the process-wide default contexts of the drop-in entry points (ctx == NULL) -------------------------------------
 // The reference's compute_ssim() is re-entrant and has no global state (src/ssim.cpp:933-1106): six caller threads get six
@@ -653,8 +661,11 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
     DeviceGuard device_guard_(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (!c->collectives.empty()) (void)comm_bounded_sync(c);      // the same bounded wait as rmgr_ssim_hip_synchronize (aborts a stuck collective)
+    else (void)hipStreamSynchronize(c->stream);
     (void)rmgr_ssim_hip_comm_destroy(c);
+    comm_forget_collectives(c);
+    for (size_t i = 0; i < c->spare_events.size(); ++i) (void)hipEventDestroy(c->spare_events[i]);
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
@@ -810,7 +821,9 @@ rmgr_int32_t rmgr_ssim_hip_enqueue_rows(rmgr_ssim_hip_Context* c, const rmgr_ssi
     if (!c || !params || !cellsDevice) return EINVAL;
     if (params->imgA.topLeft == NULL || params->imgB.topLeft == NULL) return EINVAL;
     const uint32_t W = params->width, H = params->height, cell = ssim_hip::cell_rows_for(H);
-    if (yBegin > H || (yBegin % cell) != 0) return EINVAL;                        // bands start on reduction-cell boundaries ...
+    if (yBegin > H) return EINVAL;
+    if (yRows == 0 || yBegin == H) return 0;                                      // an empty band (split_rows gives ranks beyond the image's cell rows (H, H)): nothing to do, whatever its alignment
+    if ((yBegin % cell) != 0) return EINVAL;                                      // bands start on reduction-cell boundaries ...
     const uint32_t yEnd = yRows >= H - yBegin ? H : yBegin + yRows;
     if (yEnd != H && (yEnd % cell) != 0) return EINVAL;                           // ... and end on one, or at the image's last row
     if (W == 0 || yEnd == yBegin) return 0;
@@ -930,7 +943,7 @@ rmgr_int32_t rmgr_ssim_hip_synchronize(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
     USE_DEVICE(c);
-    if (c->comm) return comm_bounded_sync(c);      // a collective may be queued: its peers might never arrive
+    if (!c->collectives.empty()) return comm_bounded_sync(c);      // an all-reduce is queued: its peers might never arrive
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1463,22 +1476,68 @@ int comm_wait_ready(Rccl* r, rmgr_ssim_hip_Context* c, ncclResult_t first)
 
 void comm_abort(Rccl* r, rmgr_ssim_hip_Context* c);
 
-// rmgr_ssim_hip_synchronize() of a context that owns a communicator: the stream may hold an all-reduce whose peers never
-// launch theirs, and hipStreamSynchronize() would then wait forever.  Poll instead; past the deadline the communicator is
-// aborted (which releases the kernel that spins on the missing peers) and the caller gets ETIMEDOUT.
+// rmgr_ssim_hip_synchronize() / _destroy() of a context that owns a communicator: the stream may hold an all-reduce whose peers never
+// launch theirs, and hipStreamSynchronize() would then wait forever.  So the wait POLLS, and it bounds the collectives only: each
+// queued all-reduce sits between two events (comm_allreduce_sums); while the oldest outstanding one has not had its turn (its
+// `begin` event is not complete) ordinary work is running and no clock ticks; from the moment `begin` completes that collective
+// has $RMGR_SSIM_HIP_COMM_TIMEOUT_S to finish; past that the communicator is aborted (ncclCommAbort releases the kernel that spins
+// on the missing peers), the wait for that kernel to leave is itself bounded by another such interval, and the caller gets
+// ETIMEDOUT.  Without ncclCommAbort nothing can release the kernel: ETIMEDOUT is returned with the stream left as it is.  The
+// poll sleeps (50 us, doubling up to 1 ms) instead of spinning.
+hipEvent_t comm_take_event(rmgr_ssim_hip_Context* c)
+{
+    hipEvent_t e = NULL;
+    if (!c->spare_events.empty()) { e = c->spare_events.back(); c->spare_events.pop_back(); return e; }
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    return e;
+}
+
+void comm_forget_collectives(rmgr_ssim_hip_Context* c)
+{
+    while (!c->collectives.empty()) {
+        c->spare_events.push_back(c->collectives.front().begin);
+        c->spare_events.push_back(c->collectives.front().end);
+        c->collectives.pop_front();
+    }
+}
+
 int comm_bounded_sync(rmgr_ssim_hip_Context* c)
 {
-    const Clock::time_point deadline = deadline_from_now(comm_timeout_s());
+    const double limit = comm_timeout_s();
+    std::chrono::microseconds nap(50);
     for (;;) {
-        const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipSuccess) return 0;
-        if (e != hipErrorNotReady) { (void)hipGetLastError(); return map_hip_error(e); }
-        if (Clock::now() > deadline) {
-            comm_abort(rccl(), c);
-            (void)hipStreamSynchronize(c->stream);           // the aborted collective's kernel exits
+        while (!c->collectives.empty()) {                        // retire what has completed
+            const hipError_t e = hipEventQuery(c->collectives.front().end);
+            if (e == hipErrorNotReady) break;
+            if (e != hipSuccess) { (void)hipGetLastError(); return map_hip_error(e); }
+            c->spare_events.push_back(c->collectives.front().begin);
+            c->spare_events.push_back(c->collectives.front().end);
+            c->collectives.pop_front();
+        }
+        if (c->collectives.empty()) {                            // nothing left on the stream can wait for a peer
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return 0;
+        }
+        rmgr_ssim_hip_Context_::Collective& k = c->collectives.front();
+        if (!k.started) {
+            const hipError_t e = hipEventQuery(k.begin);
+            if (e == hipSuccess) { k.started = true; k.since = Clock::now(); }
+            else if (e != hipErrorNotReady) { (void)hipGetLastError(); return map_hip_error(e); }
+        } else if (std::chrono::duration<double>(Clock::now() - k.since).count() > limit) {
+            Rccl* r = rccl();
+            const bool can_abort = r && r->CommAbort;
+            const hipEvent_t stuck = k.end;
+            comm_abort(r, c);
+            if (can_abort) {                                    // the aborted collective's kernel exits: wait for it, bounded
+                const Clock::time_point until = deadline_from_now(limit);
+                while (hipEventQuery(stuck) == hipErrorNotReady && Clock::now() < until) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+            (void)hipGetLastError();
+            comm_forget_collectives(c);
             return ETIMEDOUT;
         }
-        std::this_thread::yield();
+        std::this_thread::sleep_for(nap);
+        if (nap < std::chrono::microseconds(1000)) nap *= 2;
     }
 }
 
@@ -1541,8 +1600,23 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context*
     Rccl* r = rccl();
     if (!r) return ENOSYS;
     USE_DEVICE(c);
+    rmgr_ssim_hip_Context_::Collective k;
+    k.begin = comm_take_event(c); k.end = comm_take_event(c); k.started = false;
+    if (!k.begin || !k.end) { if (k.begin) c->spare_events.push_back(k.begin); return ENOMEM; }
+    HIP_TRY(hipEventRecord(k.begin, c->stream));
     const int rc = comm_wait_ready(r, c, r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
     if (rc == ETIMEDOUT) comm_abort(r, c);         // the enqueue itself never completed: the communicator is gone
+    if (rc == 0 && hipEventRecord(k.end, c->stream) == hipSuccess) {
+        c->collectives.push_back(k);               // rmgr_ssim_hip_synchronize bounds its wait for THIS collective (comm_bounded_sync)
+        while (c->collectives.size() > 64) {       // a caller that never synchronises: the oldest have long completed or will be caught by the next
+            if (hipEventQuery(c->collectives.front().end) != hipSuccess) { (void)hipGetLastError(); break; }
+            c->spare_events.push_back(c->collectives.front().begin); c->spare_events.push_back(c->collectives.front().end);
+            c->collectives.pop_front();
+        }
+    } else {
+        (void)hipGetLastError();
+        c->spare_events.push_back(k.begin); c->spare_events.push_back(k.end);
+    }
     return rc;
 }
 
@@ -1554,6 +1628,10 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_destroy(rmgr_ssim_hip_Context* c) RMG
     if (!r) { c->comm = NULL; return ENOSYS; }
     USE_DEVICE(c);
     int rc = 0;
+    if (!c->collectives.empty()) {                 // queued all-reduces first, with their deadline: a stuck one aborts the communicator
+        rc = comm_bounded_sync(c);
+        if (!c->comm) return rc;
+    }
     if (c->comm_nonblocking && r->CommFinalize) {
         // ncclCommFinalize is the asynchronous half of the teardown; ncclCommDestroy then only frees
         rc = comm_wait_ready(r, c, r->CommFinalize(c->comm));

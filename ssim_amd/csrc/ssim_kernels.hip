@@ -1382,7 +1382,17 @@ __global__ __launch_bounds__(256) void luminance_kernel(uint8_t* __restrict__ ds
                 y2 = bt601((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
                 y3 = bt601((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
             } else {
-                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3];    // R G B x, one pixel per dword
+                // R G B x, one pixel per dword.  Only bytes 0..2 of a pixel may be read (rmgr_ssim_hip_luminance_device): the dword of a
+                // row's LAST pixel would touch byte 3 -- one byte past the caller's buffer when the source pointer is offset into the
+                // pixel (ARGB with src = base + 1) and the pixel is the image's last -- so that one pixel is assembled from bytes.
+                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+                uint32_t w3;
+                if (4u * i + 4u == width) {
+                    const uint8_t* q = reinterpret_cast<const uint8_t*>(p + 3);
+                    w3 = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+                } else {
+                    w3 = p[3];
+                }
                 y0 = bt601(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
                 y1 = bt601(w1 & 255u, (w1 >> 8) & 255u, (w1 >> 16) & 255u);
                 y2 = bt601(w2 & 255u, (w2 >> 8) & 255u, (w2 >> 16) & 255u);

@@ -62,3 +62,25 @@ def test_luminance_bottom_up_rows(gpu_ctx, step):
     out, dpitch = run(gpu_ctx, host, base, step, -stride, w, h, 0, 0)
     idx = base - np.arange(h)[:, None, None] * stride + np.arange(w)[None, :, None] * step + np.arange(3)[None, None, :]
     assert np.array_equal(out[:w * h].reshape(h, w), bt601(host[idx]))
+
+
+def test_rgba_source_offset_into_the_pixel_reads_nothing_past_its_three_bytes(gpu_ctx):
+    """rmgr_ssim_hip_luminance_device may read bytes 0..2 of a pixel only.  With srcStep == 4 and the source pointer offset
+    into the pixel (ARGB: src = base + 1) the image's last pixel ends at the buffer's last byte: the four-pixels-per-thread form must
+    not load that pixel as a dword.  The allocation is EXACTLY the image (a stray read past it is at best invisible: so the values are
+    checked for widths that end on a full quad, the case that used to take the dword path, and the test mainly documents the contract)."""
+    rng = np.random.default_rng(4242)
+    for w, h in ((4, 1), (8, 3), (64, 5), (1920, 2)):
+        host = rng.integers(0, 256, 4 * w * h, dtype=np.uint8)          # A R G B per pixel, exactly sized
+        src = gpu_ctx.upload(host)
+        dst = gpu_ctx.alloc(w * h)
+        try:
+            # pixels are (R, G, B) at base + 1: the last pixel's three bytes are the buffer's last three
+            ssim_amd.api._check("rmgr_ssim_hip_luminance_device", gpu_ctx.lib.rmgr_ssim_hip_luminance_device(
+                gpu_ctx.handle, ctypes.c_void_p(dst.ptr), w, ctypes.c_void_p(src.ptr + 1), 4, 4 * w, w, h))
+            gpu_ctx.synchronize()
+            got = dst.download(np.uint8, (h, w))
+        finally:
+            src.free(); dst.free()
+        px = host.reshape(h, w, 4)[..., 1:4]
+        assert np.array_equal(got, bt601(px)), (w, h)

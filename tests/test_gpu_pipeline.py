@@ -297,6 +297,12 @@ def test_row_bands_on_separate_contexts_equal_one_launch(gpu_ctx, size):
             assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), h + cr, cr, cells.ptr) == errno.EINVAL
             assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), cr, 0xFFFFFFFF, cells.ptr) == 0      # "to the end"
             assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), 0, cr, None) == errno.EINVAL
+            # an empty band is a no-op whatever its alignment: split_rows hands ranks beyond the image's cell rows (h, h),
+            # and h is not a multiple of the cell height here
+            assert h % cr != 0 and sharding.split_rows(h, cr, plan.cellsY + 3)[-1] == (h, h)
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), h, 0, cells.ptr) == 0
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), h, cr, cells.ptr) == 0
+            assert lib.rmgr_ssim_hip_enqueue_rows(gpu_ctx.handle, ctypes.byref(p), cr + 1, 0, cells.ptr) == 0
             gpu_ctx.synchronize()
         finally:
             gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
