@@ -22,6 +22,7 @@
 #include <new>
 #include <thread>
 #include <deque>
+#include <string>
 #include <vector>
 
 using ssim_hip::PairDesc;
@@ -1300,16 +1301,36 @@ template <typename F> void sym(void* h, const char* name, F& f) { f = reinterpre
 // Which librccl: $RMGR_SSIM_HIP_RCCL_LIB if set; else the SONAME first -- a process that already carries an RCCL (a host
 // framework that bundles its own copy next to its own HIP runtime, e.g. a PyTorch wheel) must get THAT copy back, not a
 // second RCCL bound to a second HIP runtime -- then the development name and ROCm's default location.
-Rccl* rccl()
+// NEVER waits: the first caller loads (dlopen + dlsym, on whichever thread that is -- normally a communicator helper); while that
+// is in progress every other caller gets NULL (-> ENOSYS / "not loadable yet") instead of queueing behind a load that an
+// abandoned helper might be stuck in (std::call_once made every later caller wait without a bound).
+// path_override: $RMGR_SSIM_HIP_RCCL_LIB as the CALLER's thread read it (helpers do not call getenv: the host process -- Python --
+// may be changing its environment concurrently).
+enum { RCCL_UNLOADED = 0, RCCL_LOADING = 1, RCCL_READY = 2, RCCL_ABSENT = 3 };
+Rccl             g_rccl_api;
+std::atomic<int> g_rccl_state(RCCL_UNLOADED);
+
+// wait_for_load (communicator helpers only -- their caller bounds THEM): sleep through another thread's load instead of reporting NULL.
+Rccl* rccl(const char* path_override = NULL, bool use_env = true, bool wait_for_load = false)
 {
-    static Rccl api;
-    static std::once_flag once;
-    std::call_once(once, []() {
-        memset(&api, 0, sizeof(api));
-        const char* names[] = {getenv("RMGR_SSIM_HIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !api.handle; ++i)
-            if (names[i] && names[i][0]) api.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-        if (!api.handle) return;
+    for (;;) {
+        const int st = g_rccl_state.load(std::memory_order_acquire);
+        if (st == RCCL_READY) return &g_rccl_api;
+        if (st == RCCL_ABSENT) return NULL;
+        if (st == RCCL_LOADING) {
+            if (!wait_for_load) return NULL;
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            continue;
+        }
+        int expected = RCCL_UNLOADED;
+        if (g_rccl_state.compare_exchange_strong(expected, RCCL_LOADING)) break;
+    }
+    Rccl& api = g_rccl_api;
+    memset(&api, 0, sizeof(api));
+    const char* names[] = {path_override ? path_override : (use_env ? getenv("RMGR_SSIM_HIP_RCCL_LIB") : NULL), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]) && !api.handle; ++i)
+        if (names[i] && names[i][0]) api.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (api.handle) {
         sym(api.handle, "ncclGetVersion", api.GetVersion);
         sym(api.handle, "ncclGetUniqueId", api.GetUniqueId);
         sym(api.handle, "ncclCommInitRank", api.CommInitRank);
@@ -1320,11 +1341,14 @@ Rccl* rccl()
         sym(api.handle, "ncclCommCount", api.CommCount);
         sym(api.handle, "ncclAllReduce", api.AllReduce);
         sym(api.handle, "ncclCommDestroy", api.CommDestroy);
-        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.CommCount) { dlclose(api.handle); api.handle = NULL; return; }
+        if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy || !api.CommCount) { dlclose(api.handle); api.handle = NULL; }
+    }
+    if (api.handle) {
         if (api.GetVersion) (void)api.GetVersion(&api.version);
         Dl_info info;
         if (dladdr(reinterpret_cast<void*>(api.AllReduce), &info) && info.dli_fname) snprintf(api.path, sizeof(api.path), "%s", info.dli_fname);
-    });
+    }
+    g_rccl_state.store(api.handle ? RCCL_READY : RCCL_ABSENT, std::memory_order_release);
     return api.handle ? &api : NULL;
 }
 
@@ -1358,10 +1382,16 @@ Clock::time_point deadline_from_now(double seconds)
     return Clock::now() + std::chrono::duration_cast<Clock::duration>(std::chrono::duration<double>(seconds));
 }
 
-// $RMGR_SSIM_HIP_COMM_DEBUG=1: the helper thread reports its steps on stderr (where a stalled bootstrap stalled).
-void comm_debug(const char* what, double seconds = -1.0)
+// $RMGR_SSIM_HIP_COMM_DEBUG=1: the helper thread reports its steps on stderr (where a stalled bootstrap stalled).  The variable
+// is read on the CALLER's thread (comm_debug_wanted) and travels in the job: helpers never call getenv.
+bool comm_debug_wanted()
 {
-    static const bool on = getenv("RMGR_SSIM_HIP_COMM_DEBUG") && atoi(getenv("RMGR_SSIM_HIP_COMM_DEBUG")) != 0;
+    const char* e = getenv("RMGR_SSIM_HIP_COMM_DEBUG");
+    return e && atoi(e) != 0;
+}
+
+void comm_debug(bool on, const char* what, double seconds = -1.0)
+{
     if (!on) return;
     if (seconds >= 0.0) fprintf(stderr, "[rmgr-ssim comm] %s (%.3f s)\n", what, seconds);
     else                fprintf(stderr, "[rmgr-ssim comm] %s\n", what);
@@ -1382,22 +1412,24 @@ struct CommJob {
     // inputs
     int device, rank_count, rank;
     bool want_id, nonblocking_ok;
+    bool debug;                    // $RMGR_SSIM_HIP_COMM_DEBUG, read by the caller
+    std::string rccl_path;         // $RMGR_SSIM_HIP_RCCL_LIB, read by the caller ("" = unset)
     ncclUniqueId id;
     // outputs
     ncclComm_t comm;
     bool nonblocking;
-    CommJob() : done(false), abandoned(false), cancel(false), rc(0), device(0), rank_count(0), rank(0), want_id(false), nonblocking_ok(true), comm(NULL), nonblocking(false) { memset(&id, 0, sizeof(id)); }
+    CommJob() : done(false), abandoned(false), cancel(false), rc(0), device(0), rank_count(0), rank(0), want_id(false), nonblocking_ok(true), debug(false), comm(NULL), nonblocking(false) { memset(&id, 0, sizeof(id)); }
 };
 
 void comm_job_body(const std::shared_ptr<CommJob>& j)
 {
     const Clock::time_point t0 = Clock::now();
     int rc = 0;
-    comm_debug("helper: loading librccl");
-    Rccl* r = rccl();                                        // may load (and page in) half a gigabyte of library
-    comm_debug(r ? r->path : "helper: no usable librccl", seconds_since(t0));
+    comm_debug(j->debug, "helper: loading librccl");
+    Rccl* r = rccl(j->rccl_path.empty() ? NULL : j->rccl_path.c_str(), false, true);      // may load (and page in) half a gigabyte of library; no getenv here
+    comm_debug(j->debug, r ? r->path : "helper: no usable librccl", seconds_since(t0));
     if (!r) rc = ENOSYS;
-    else if (j->want_id) { rc = map_nccl(r->GetUniqueId(&j->id)); comm_debug("helper: ncclGetUniqueId returned", seconds_since(t0)); }
+    else if (j->want_id) { rc = map_nccl(r->GetUniqueId(&j->id)); comm_debug(j->debug, "helper: ncclGetUniqueId returned", seconds_since(t0)); }
     else if (hipSetDevice(j->device) != hipSuccess) { (void)hipGetLastError(); rc = ENODEV; }
     else {
         ncclResult_t res;
@@ -1407,7 +1439,7 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
             res = r->CommInitRankConfig(&j->comm, j->rank_count, j->id, j->rank, &cfg);
             char msg[96];
             snprintf(msg, sizeof(msg), "helper: ncclCommInitRankConfig(blocking = 0) returned %d", (int)res);
-            comm_debug(msg, seconds_since(t0));
+            comm_debug(j->debug, msg, seconds_since(t0));
             // An error here is final (no second attempt with the plain call: the id's rendezvous has been used).
             if (res == ncclSuccess || res == ncclInProgress) {
                 j->nonblocking = true;
@@ -1419,12 +1451,12 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
                     if (j->cancel.load()) { res = ncclInProgress; break; }      // the caller's deadline passed
                     std::this_thread::sleep_for(std::chrono::microseconds(200));
                 }
-                comm_debug(res == ncclSuccess ? "helper: communicator ready" : res == ncclInProgress ? "helper: deadline passed, aborting the communicator" : "helper: init failed, aborting the communicator", seconds_since(t0));
-                if (res != ncclSuccess && j->comm) { (void)r->CommAbort(j->comm); j->comm = NULL; comm_debug("helper: ncclCommAbort returned", seconds_since(t0)); }
+                comm_debug(j->debug, res == ncclSuccess ? "helper: communicator ready" : res == ncclInProgress ? "helper: deadline passed, aborting the communicator" : "helper: init failed, aborting the communicator", seconds_since(t0));
+                if (res != ncclSuccess && j->comm) { (void)r->CommAbort(j->comm); j->comm = NULL; comm_debug(j->debug, "helper: ncclCommAbort returned", seconds_since(t0)); }
             }
         } else {
             res = r->CommInitRank(&j->comm, j->rank_count, j->id, j->rank);
-            comm_debug("helper: ncclCommInitRank returned", seconds_since(t0));
+            comm_debug(j->debug, "helper: ncclCommInitRank returned", seconds_since(t0));
         }
         if (res != ncclSuccess) j->comm = NULL;
         rc = map_nccl(res);
@@ -1438,7 +1470,7 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
     if (orphan) {
         if (r && r->CommAbort) (void)r->CommAbort(j->comm);
         j->comm = NULL;
-        comm_debug("helper: late communicator aborted", seconds_since(t0));
+        comm_debug(j->debug, "helper: late communicator aborted", seconds_since(t0));
     }
 }
 
@@ -1447,6 +1479,8 @@ void comm_job_body(const std::shared_ptr<CommJob>& j)
 // RCCL's bootstrap thread winds down -- and is left to finish that on its own (detached; it owns everything it touches).
 int run_comm_job(const std::shared_ptr<CommJob>& j, double timeout_s)
 {
+    j->debug = comm_debug_wanted();                           // the environment is read HERE, on the caller's thread
+    if (const char* e = getenv("RMGR_SSIM_HIP_RCCL_LIB")) { try { j->rccl_path = e; } catch (...) { return ENOMEM; } }
     std::thread t;
     try { t = std::thread(comm_job_body, j); } catch (...) { return EAGAIN; }
     std::unique_lock<std::mutex> lk(j->m);
