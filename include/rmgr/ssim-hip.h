@@ -253,7 +253,11 @@ rmgr_int32_t rmgr_ssim_hip_luminance_device(rmgr_ssim_hip_Context* ctx, rmgr_uin
  * aborted (ncclCommAbort) by the helper.  On the RCCL builds of this image (2.26.6 in the PyTorch wheel, 2.27.7 in
  * /opt/rocm) that call carries the rendezvous out before it returns, blocking = 0 notwithstanding (measured:
  * profiles/r04_final_rccl_selftest.txt), so what bounds comm_init there is the helper's timeout: the helper stays parked
- * inside RCCL and is abandoned (one idle thread; nothing it touches lives on the caller's stack).
+ * inside RCCL and is abandoned (one idle thread; nothing it touches lives on the caller's stack).  Caveats of an abandoned helper: it is
+ * still inside librccl when the process exits or this library is unloaded (exit from main is safe -- the thread is never joined and owns
+ * its data --, dlclose() of this library while it exists is not); and while a FIRST use is still loading librccl on another thread,
+ * comm_describe / comm_allreduce_sums / comm_destroy report "not loadable" / ENOSYS instead of waiting for that load.  Helpers never read
+ * the environment: $RMGR_SSIM_HIP_RCCL_LIB, _COMM_DEBUG and _COMM_TIMEOUT_S are read on the calling thread of each entry point.
  * $RMGR_SSIM_HIP_COMM_BLOCKING=1 asks for a plain blocking communicator; $RMGR_SSIM_HIP_COMM_DEBUG=1 logs the helper's
  * steps on stderr.
  */
