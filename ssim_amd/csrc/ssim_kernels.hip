@@ -33,8 +33,13 @@
 
 // Cache policy of the map stores: nt (non-temporal).  The map is written once and never read by the kernel; as ordinary
 // write-back lines it competes with the input rows for L2 and costs the separable mode 18 % with a map (8192^2: 333 -> 391 Gpix/s
-// with nt; MODE_EXACT +2.7 %; profiles/r02_map_store_ab.txt).
+// with nt; MODE_EXACT +2.7 %; profiles/r02_map_store_ab.txt).  Round 5 re-measured 0 (default) / 1 (sc0) / 2 (nt) / 3 (sc0 nt) /
+// 18 (sc1 nt) on 2 x 8192^2: 369 / 371 / 395 / 392 / 395 Gpix/s separable, 196 / - / 200 / 200 / 199 exact: nt, any flavour
+// (profiles/r05_prefetch_and_map_store_ab.txt).  What the map still costs -- 6...7 % in every mode against the same launch without
+// it -- is neither its instructions (one store + ~8 scalar per row) nor the pixel loads' latency (a second row in flight: +-0).
+#ifndef SSIM_MAP_STORE_AUX
 #define SSIM_MAP_STORE_AUX 2
+#endif
 
 namespace ssim_hip {
 namespace {
@@ -696,7 +701,8 @@ void ssim_strip2_kernel(const KArgs args)
     }
 
     // One row of pixels is in flight in registers (requested an iteration, ~1 us, before it is staged).
-    // A second row in flight was measured: no gain in MODE_EXACT, -3 % in the separable mode (registers).
+    // A second row in flight was measured twice: round 1 (no gain in MODE_EXACT, -3 % in the separable mode: registers) and round 5
+    // (registers to spare by then; +-0 with and without the map in every mode: profiles/r05_prefetch_and_map_store_ab.txt).
     uint8_t va[NLOAD], vb[NLOAD];
     auto fetch_to = [&](int r, uint8_t (&oa)[NLOAD], uint8_t (&ob)[NLOAD]) {  // row r (clamped: src/ssim.cpp:562-582) -> registers
         const int ry = r < 0 ? 0 : (r > H - 1 ? H - 1 : r);
