@@ -42,5 +42,11 @@ done
   timeout 300 python3 tools/ab.py 8 4096 0 0 1 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode 0 one-column kernel:/"
 } > "$OUT/mode_speeds.txt" 2>&1
 timeout 900 python3 tests/tools/error_table.py > "$OUT/error_table.md" 2> "$OUT/error_table.err"
+# round 5: what a first call costs, what concurrent callers get, and the long parity runs of the final kernels
+{ for w in plain split cli plain split; do timeout 120 python3 tools/cold_start_probe.py $w; done; } > "$OUT/cold_start.txt" 2>&1
+{ for cfg in "4096 1" "4096 0" "1920 1"; do echo "# size map: $cfg"; timeout 120 python3 tools/concurrent_callers.py $cfg 1,2,4,6 1.5; done; echo "# RMGR_SSIM_HIP_POOL=1"; RMGR_SSIM_HIP_POOL=1 timeout 120 python3 tools/concurrent_callers.py 4096 1 1,4 1.5; } > "$OUT/concurrent_callers.txt" 2>&1
+{ time timeout 900 python3 tests/tools/soak.py 30000 20261003; } > "$OUT/soak.txt" 2>&1
+timeout 900 python3 tests/tools/fullsize_check.py > "$OUT/fullsize_check.txt" 2>&1
+timeout 300 python3 tools/balanced_check.py > "$OUT/balanced_check.txt" 2>&1
 find "$OUT" -name "*.csv" | wc -l
 du -sh "$OUT"

@@ -21,7 +21,8 @@ cp $P/trace/t_kernel_stats.csv profiles/${R}_final_bench_kernel_stats.csv
 python3 tools/summarize_prof.py "round ${R#r0}, final kernel: rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline (32 x 4096^2 per step; 20 timed steps + gate, clock-settle and warm-up launches; also the fast-mode and single-pair legs)" $P/trace/t_kernel_trace.csv > profiles/${R}_final_bench_kernel_trace.md
 cp $P/mode_speeds.txt profiles/${R}_final_mode_speeds.txt
 cp $P/error_table.md profiles/${R}_error_table.md
-for f in bench_rccl_1rank.json bench_rccl_1rank_torch.json bench_c4_strong.json host_call_probe.txt latency_probe.txt rccl_selftest.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_final_$f; done
+for f in bench_rccl_1rank.json bench_rccl_1rank_torch.json bench_c4_strong.json host_call_probe.txt latency_probe.txt rccl_selftest.txt cold_start.txt concurrent_callers.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_final_$f; done
+for f in soak.txt fullsize_check.txt balanced_check.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_$f; done
 python3 - "$P" "$R" <<'PY'
 import csv, hashlib, json, sys
 P, R = sys.argv[1], sys.argv[2]
