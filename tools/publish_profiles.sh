@@ -37,5 +37,5 @@ t = {"kernel_source_sha256": hashlib.sha256(open("ssim_amd/csrc/ssim_kernels.hip
      "_comment": "kernel_source_sha256 = the ssim_kernels.hip these passes ran (bench.py quotes the figures for that version only: rmgr_ssim_hip_get_kernel_source_id). HBM bytes per launch measured with rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per profiles/r01_fetch_size_calibration.md), expressed per image pair so bench.py can scale to its batch. Sources: profiles/%s_final_exact_4k_pmc.md, %s_final_exact_8k_map_pmc.md, %s_final_exact_1080p_pmc.md" % (R, R, R),
      "exact_4096_nomap": entry("4k", 32, 2 * 4096 * 4096), "exact_8192_map": entry("8kmap", 2, 6 * 8192 * 8192), "exact_1080p_nomap": entry("1080p", 32, 2 * 1920 * 1080)}
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps({k: v["ratio"] for k, v in t.items() if k[0] != "_"}))
+print(json.dumps({k: v["ratio"] for k, v in t.items() if isinstance(v, dict)}))
 PY
