@@ -50,7 +50,7 @@ class Plan(ctypes.Structure):
                 ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32)]
 
 
-ABI_VERSION = 4      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
+ABI_VERSION = 5      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
 
 
 class ThreadPool(ctypes.Structure):
