@@ -71,8 +71,8 @@ const char* rmgr_ssim_hip_get_kernel_source_id(void) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT;
 
 /* An engine instance: one device, one stream, its own grow-only scratch.  A context may be used by one
- * host thread at a time (create one per thread, or serialise); the NULL / default context of the
- * host-pointer entry points is shared process-wide and locked internally. */
+ * host thread at a time (create one per thread, or serialise); ctx == NULL entry points lease one of the
+ * process-wide default contexts per call (rmgr_ssim_hip_compute_ssim_host) and may be called from any number of threads. */
 typedef struct rmgr_ssim_hip_Context_ rmgr_ssim_hip_Context;
 
 /* Number of usable HIP devices (0 when none; never fails). */
@@ -83,8 +83,9 @@ rmgr_int32_t rmgr_ssim_hip_get_device_count(rmgr_int32_t* count) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** ctx, rmgr_int32_t device, void* stream) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 
-/* ctx == NULL (set and get): the process-wide default context the unchanged rmgr_ssim_compute_ssim() runs on (created on
- * first use; ENODEV without a device).  This is what rmgr::ssim::select_impl() calls (src/ssim.cpp:808-896). */
+/* ctx == NULL (set and get): the arithmetic mode of the process-wide default contexts the unchanged rmgr_ssim_compute_ssim() runs on
+ * (a property of their pool, applied when a call leases one; the first is created on first use: ENODEV without a device).  This is what
+ * rmgr::ssim::select_impl() calls (src/ssim.cpp:808-896). */
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mode) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
 
