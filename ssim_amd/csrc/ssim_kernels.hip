@@ -36,7 +36,9 @@
 // with nt; MODE_EXACT +2.7 %; profiles/r02_map_store_ab.txt).  Round 5 re-measured 0 (default) / 1 (sc0) / 2 (nt) / 3 (sc0 nt) /
 // 18 (sc1 nt) on 2 x 8192^2: 369 / 371 / 395 / 392 / 395 Gpix/s separable, 196 / - / 200 / 200 / 199 exact: nt, any flavour
 // (profiles/r05_prefetch_and_map_store_ab.txt).  What the map still costs -- 6...7 % in every mode against the same launch without
-// it -- is neither its instructions (one store + ~8 scalar per row) nor the pixel loads' latency (a second row in flight: +-0).
+// it -- is neither its instructions (stores issued with a zero-record descriptor are free), nor HBM or the TLB (all rows folded onto
+// eight cache-resident ones: the full cost), nor the pixel loads' latency (a second row in flight: +-0): it is proportional to the
+// bytes that leave the CU (half the rows, or half the lanes: half the cost), and the float map is the contract.
 #ifndef SSIM_MAP_STORE_AUX
 #define SSIM_MAP_STORE_AUX 2
 #endif
