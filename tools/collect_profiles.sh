@@ -6,6 +6,19 @@ cd "$(dirname "$0")/.."
 OUT=gpurun_out/${1:-prof_final}
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
+# PMC passes FIRST: profiles/traffic.json is regenerated from them on this box, for the kernel source in this tree, so that the bench lines below carry roofline.traffic
+pmc() {   # name, counters, target args...
+  local name=$1 ctrs=$2; shift 2
+  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
+}
+for cfg in "4k 32 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
+  set -- $cfg; tag=$1; shift
+  pmc ${tag}_fetch FETCH_SIZE "$@"
+  pmc ${tag}_write WRITE_SIZE "$@"
+  pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
+  pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
+done
+python3 tools/make_traffic_json.py "$OUT" r05 profiles/traffic.json > "$OUT/traffic_ratios.json" && cp profiles/traffic.json "$OUT/traffic.json"
 for wl in 4k 8k-map 1080p; do
   timeout 600 python3 bench.py --workload $wl > "$OUT/bench_$wl.log" 2>&1
   grep '"metric"' "$OUT/bench_$wl.log" > "$OUT/bench_$wl.json"
@@ -23,17 +36,6 @@ timeout 150 python3 tools/rccl_selftest.py single --with-torch 2>&1 | grep "rccl
 timeout 300 python3 tools/host_call_probe.py 4096 1,8 > "$OUT/host_call_probe.txt" 2>&1
 timeout 300 python3 tools/latency_probe.py > "$OUT/latency_probe.txt" 2>&1
 grep '"metric"' "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json"
-pmc() {   # name, counters, target args...
-  local name=$1 ctrs=$2; shift 2
-  timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
-}
-for cfg in "4k 32 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
-  set -- $cfg; tag=$1; shift
-  pmc ${tag}_fetch FETCH_SIZE "$@"
-  pmc ${tag}_write WRITE_SIZE "$@"
-  pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
-  pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
-done
 # kernel-only speeds per mode (HIP events, tools/ab.py): batch of 8, single pair, with map
 {
   for m in 0 3 1 4 2; do timeout 300 python3 tools/ab.py 8 4096 $m 0 0 3 0 | tail -1 | sed "s/^/8 x 4096^2 mode $m:/"; done

@@ -23,19 +23,5 @@ cp $P/mode_speeds.txt profiles/${R}_final_mode_speeds.txt
 cp $P/error_table.md profiles/${R}_error_table.md
 for f in bench_rccl_1rank.json bench_rccl_1rank_torch.json bench_c4_strong.json host_call_probe.txt latency_probe.txt rccl_selftest.txt cold_start.txt concurrent_callers.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_final_$f; done
 for f in soak.txt fullsize_check.txt balanced_check.txt; do [ -f $P/$f ] && cp $P/$f profiles/${R}_$f; done
-python3 - "$P" "$R" <<'PY'
-import csv, hashlib, json, sys
-P, R = sys.argv[1], sys.argv[2]
-def ctr(tag, name):
-    rows = [float(r["Counter_Value"]) for r in csv.DictReader(open("%s/%s/t_counter_collection.csv" % (P, tag))) if "ssim_strip" in r["Kernel_Name"] and r["Counter_Name"] == name]
-    return sum(rows) / len(rows)
-def entry(tag, pairs, alg):
-    f, w = ctr(tag + "_fetch", "FETCH_SIZE"), ctr(tag + "_write", "WRITE_SIZE")
-    b = (2 * f + w) * 1024 / pairs
-    return {"pairs": pairs, "fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "bytes_per_pair": round(b, 1), "algorithmic_bytes_per_pair": alg, "ratio": round(b / alg, 3)}
-t = {"kernel_source_sha256": hashlib.sha256(open("ssim_amd/csrc/ssim_kernels.hip", "rb").read()).hexdigest(),
-     "_comment": "kernel_source_sha256 = the ssim_kernels.hip these passes ran (bench.py quotes the figures for that version only: rmgr_ssim_hip_get_kernel_source_id). HBM bytes per launch measured with rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per profiles/r01_fetch_size_calibration.md), expressed per image pair so bench.py can scale to its batch. Sources: profiles/%s_final_exact_4k_pmc.md, %s_final_exact_8k_map_pmc.md, %s_final_exact_1080p_pmc.md" % (R, R, R),
-     "exact_4096_nomap": entry("4k", 32, 2 * 4096 * 4096), "exact_8192_map": entry("8kmap", 2, 6 * 8192 * 8192), "exact_1080p_nomap": entry("1080p", 32, 2 * 1920 * 1080)}
-json.dump(t, open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps({k: v["ratio"] for k, v in t.items() if isinstance(v, dict)}))
-PY
+# traffic.json as the GPU box wrote it (stamped with the kernel source the passes ran); regenerated here only for collections that predate that step
+if [ -f $P/traffic.json ]; then cp $P/traffic.json profiles/traffic.json; else python3 tools/make_traffic_json.py "$P" "$R"; fi
