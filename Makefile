@@ -35,16 +35,16 @@ $(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_d
 	objcopy --wildcard --keep-global-symbol='rmgr_ssim_*' --keep-global-symbol='_ZN4rmgr4ssim12compute_ssimE*' --keep-global-symbol='_ZN4rmgr4ssim11select_implE*' $(OBJ)/rmgr_ssim_api.o
 	rm -f $@ && ar rcs $@ $(OBJ)/rmgr_ssim_api.o
 
-# The reference's second archive (CMakeLists.txt:229: rmgr-ssim-openmp = src/ssim-openmp.c).  Here the OpenMP entry
-# point is a forwarder that lives in ssim_dropin.o already; the archive exists so that a link line written for the
-# reference (-lrmgr-ssim-openmp -lrmgr-ssim) resolves unchanged.  It carries one marker object.
-$(OUT)/librmgr-ssim-openmp.a: $(OBJ)/ssim_openmp_marker.o
+# The reference's second archive (CMakeLists.txt:229: rmgr-ssim-openmp = src/ssim-openmp.c): rmgr_ssim_compute_ssim_openmp() and
+# nothing else, resolved against librmgr-ssim like the reference's (-lrmgr-ssim-openmp -lrmgr-ssim); the shared libraries carry
+# the same object.
+$(OUT)/librmgr-ssim-openmp.a: $(OBJ)/ssim_openmp.o
 	@mkdir -p $(OUT)
 	rm -f $@ && ar rcs $@ $^
 
-$(OBJ)/ssim_openmp_marker.o: $(SRC)/ssim_openmp_marker.c
+$(OBJ)/ssim_openmp.o: $(SRC)/ssim_openmp.c include/rmgr/ssim-openmp.h include/rmgr/ssim.h
 	@mkdir -p $(OBJ)
-	$(CC) -std=c89 -pedantic -O2 -fPIC -Wall -Iinclude -c $< -o $@
+	$(CC) -std=c89 -pedantic -O2 -fPIC -Wall -Wextra -Iinclude -c $< -o $@
 
 # The kernels carry the sha256 of their own source (rmgr_ssim_hip_get_kernel_source_id): measurements that belong to one version of
 # the kernels -- profiles/traffic.json -- name it, and bench.py refuses to quote them for any other.
@@ -64,7 +64,7 @@ $(OBJ)/ssim_dropin.o: $(SRC)/ssim_dropin.cpp $(SRC)/ssim_internal.h include/rmgr
 # Only the API leaves the shared libraries: $(SRC)/exports.map (the reference's archive exposes only its API as well).
 EXPORTS := -Wl,--version-script=$(SRC)/exports.map
 
-$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o $(SRC)/exports.map
+$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 
@@ -76,7 +76,7 @@ $(OBJ)/ssim_hip_abi_double.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h incl
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRMGR_SSIM_USE_DOUBLE=1 -x hip -c $< -o $@
 
-$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o $(SRC)/exports.map
+$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 

@@ -78,11 +78,7 @@ extern "C" rmgr_int32_t rmgr_ssim_compute_ssim(float* ssim, const rmgr_ssim_Para
     return rmgr_ssim_hip_compute_ssim_host(NULL, ssim, params, threadPool);
 }
 
-extern "C" rmgr_int32_t rmgr_ssim_compute_ssim_openmp(float* ssim, const rmgr_ssim_Params* params) RMGR_NOEXCEPT
-{
-    // The reference builds an all-cores thread pool here; the GPU grid plays that role.
-    return rmgr_ssim_hip_compute_ssim_host(NULL, ssim, params, NULL);
-}
+// rmgr_ssim_compute_ssim_openmp(): ssim_openmp.c (an archive of its own, like the reference's src/ssim-openmp.c)
 
 namespace rmgr { namespace ssim
 {

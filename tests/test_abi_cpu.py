@@ -50,11 +50,17 @@ def test_library_exports_nothing_but_the_api(name):
 def test_static_archive_exposes_nothing_but_the_api():
     """The archive under the reference's name (librmgr-ssim.a): one relocatable object whose global definitions are the
     declared API, as in the shared libraries -- a program that links it must not see (or collide with) ssim_hip::*."""
-    path = os.path.join(os.path.dirname(ssim_amd.LIB_PATH), "librmgr-ssim.a")
-    out = subprocess.run(["nm", "--defined-only", "-g", path], capture_output=True, text=True, check=True).stdout
-    exported = set(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3)
-    allowed = declared_c_functions() | set(ssim_amd.CXX_SYMBOLS)
-    assert exported == allowed, (sorted(exported - allowed), sorted(allowed - exported))
+    libdir = os.path.dirname(ssim_amd.LIB_PATH)
+
+    def exported(path):
+        out = subprocess.run(["nm", "--defined-only", "-g", path], capture_output=True, text=True, check=True).stdout
+        return set(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3)
+    # the reference's split (CMakeLists.txt:205, :229): rmgr_ssim_compute_ssim_openmp is the one function of the second archive
+    openmp = {"rmgr_ssim_compute_ssim_openmp"}
+    allowed = (declared_c_functions() | set(ssim_amd.CXX_SYMBOLS)) - openmp
+    got = exported(os.path.join(libdir, "librmgr-ssim.a"))
+    assert got == allowed, (sorted(got - allowed), sorted(allowed - got))
+    assert exported(os.path.join(libdir, "librmgr-ssim-openmp.a")) == openmp
 
 
 @pytest.mark.parametrize("cxx", ["g++", "/opt/rocm/lib/llvm/bin/clang++"])
@@ -211,7 +217,7 @@ def test_no_device_fails_loudly_never_computes():
 def build_dropin_client(tmp_path, static=False):
     exe = tmp_path / ("dropin_client_static" if static else "dropin_client")
     libdir = os.path.dirname(ssim_amd.LIB_PATH)
-    link = ([os.path.join(libdir, "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"] if static
+    link = ([os.path.join(libdir, "librmgr-ssim-openmp.a"), os.path.join(libdir, "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"] if static
             else ["-L", libdir, "-lrmgr-ssim-hip", "-Wl,-rpath," + libdir])
     subprocess.run(["g++", "-std=c++98", "-pedantic", "-Wall", "-Werror", "-I", INCLUDE,
                     os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe)] + link, check=True)
@@ -242,11 +248,12 @@ def test_install_layout_and_reference_link_line(tmp_path):
                     "-L", str(prefix / "lib"), "-lrmgr-ssim-openmp", "-lrmgr-ssim", "-Wl,-rpath," + str(prefix / "lib")], check=True)
     r = subprocess.run([str(prefix / "bin" / "rmgr-ssim"), "-h"], capture_output=True, text=True)
     assert r.returncode == 0 and "Usage: rmgr-ssim" in r.stdout
-    # the static archive under the reference's name links too (plus the HIP runtime it depends on)
+    # the static archives under the reference's names link too (plus the HIP runtime they depend on); the client calls
+    # rmgr_ssim_compute_ssim_openmp, which -- as in the reference -- lives in the second archive
     assert (prefix / "lib" / "librmgr-ssim.a").exists()
     exe_static = tmp_path / "client_static"
     subprocess.run(["g++", "-std=c++98", "-I", str(prefix / "include"), os.path.join(ROOT, "tests", "dropin_client.cpp"), "-o", str(exe_static),
-                    str(prefix / "lib" / "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+                    str(prefix / "lib" / "librmgr-ssim-openmp.a"), str(prefix / "lib" / "librmgr-ssim.a"), "-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-lpthread", "-Wl,-rpath,/opt/rocm/lib"], check=True)
     # ... and so does the reference's pair of archives by name (CMakeLists.txt:205, :229), forced static
     assert (prefix / "lib" / "librmgr-ssim-openmp.a").exists()
     exe_pair = tmp_path / "client_static_pair"
