@@ -537,6 +537,7 @@ int pool_acquire(rmgr_ssim_hip_Context** out)
 {
     std::unique_lock<std::mutex> lk(g_pool.m);
     pool_configure_locked();
+    bool create_failed_here = false;     // this call tried to grow the pool and could not (out of memory ...): it waits for a lease instead of trying again
     for (;;) {
         if (!g_pool.idle.empty()) {
             *out = g_pool.idle.back();
@@ -545,7 +546,7 @@ int pool_acquire(rmgr_ssim_hip_Context** out)
             return 0;
         }
         if (g_pool.create_err && g_pool.all.empty()) return g_pool.create_err;      // no device: every call fails the same way, at once
-        if ((int)g_pool.all.size() < g_pool.limit) {
+        if ((int)g_pool.all.size() < g_pool.limit && !create_failed_here) {
             g_pool.all.push_back(NULL);                                             // reserve a slot; create outside the lock
             lk.unlock();
             rmgr_ssim_hip_Context* c = NULL;
@@ -556,14 +557,16 @@ int pool_acquire(rmgr_ssim_hip_Context** out)
                 g_pool.create_err = rc ? rc : ENODEV;
                 g_pool.freed.notify_all();
                 if (g_pool.all.empty()) return g_pool.create_err;
-                continue;                                                           // others exist: wait for one of them
+                create_failed_here = true;
+                continue;                                                           // others exist (or are being created): wait for one of them
             }
             *std::find(g_pool.all.begin(), g_pool.all.end(), (rmgr_ssim_hip_Context*)NULL) = c;
             c->mode = g_pool.mode;
             *out = c;
             return 0;
         }
-        g_pool.freed.wait(lk);
+        if (g_pool.all.empty()) return g_pool.create_err ? g_pool.create_err : ENODEV;      // nothing exists and nothing is being created: no lease will ever come
+        g_pool.freed.wait(lk);                                                      // a context exists or is being created: its release (or its failure) wakes this call
     }
 }
 
@@ -1637,7 +1640,11 @@ extern "C" rmgr_int32_t rmgr_ssim_hip_comm_allreduce_sums(rmgr_ssim_hip_Context*
     rmgr_ssim_hip_Context_::Collective k;
     k.begin = comm_take_event(c); k.end = comm_take_event(c); k.started = false;
     if (!k.begin || !k.end) { if (k.begin) c->spare_events.push_back(k.begin); return ENOMEM; }
-    HIP_TRY(hipEventRecord(k.begin, c->stream));
+    if (hipEventRecord(k.begin, c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        c->spare_events.push_back(k.begin); c->spare_events.push_back(k.end);
+        return ECHILD;
+    }
     const int rc = comm_wait_ready(r, c, r->AllReduce(sumsDevice, sumsDevice, count, ncclFloat64, ncclSum, c->comm, c->stream));
     if (rc == ETIMEDOUT) comm_abort(r, c);         // the enqueue itself never completed: the communicator is gone
     if (rc == 0 && hipEventRecord(k.end, c->stream) == hipSuccess) {
