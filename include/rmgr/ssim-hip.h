@@ -56,7 +56,7 @@ extern "C" {
  *   3  round 3: MODE_FAST (1) became the hybrid, the all-separable arithmetic moved to MODE_SEPARABLE (4); Plan grew by two fields
  *   4  round 4: Plan carries structSize (first field) and the cell grid; rmgr_ssim_hip_comm_* calls are bounded by a deadline
  *      (ETIMEDOUT), comm_rank_count / comm_describe added; row-band entry points (enqueue_rows, reduce_cells) added
- *   5  round 5: MODE_SEPARABLE (4) forms its quotient as n * rcp(d): its values moved by <= 3 ulp (contract unchanged); ctx == NULL calls
+ *   5  round 5: MODE_FAST (1) and MODE_SEPARABLE (4) form their quotient as n * rcp(d): their values moved by <= 3 ulp (contracts unchanged); ctx == NULL calls
  *      run on a pool of default contexts and no longer serialise; Plan grew by balancedChunks / balancedChunkRows (harmless: structSize);
  *      the deadline of synchronize / destroy applies per queued all-reduce; get_default_pool, get_kernel_source_id added */
 #define RMGR_SSIM_HIP_ABI_VERSION 5

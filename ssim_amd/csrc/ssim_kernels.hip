@@ -238,13 +238,18 @@ __device__ __forceinline__ void blur_separable_pair(V (&accA)[11], V (&accB)[11]
 
 // Per-pixel SSIM, unfused fp32 exactly as src/ssim.cpp:681-693 / src/ssim_avx.cpp:342-352.
 // 2*x + c is written as fma(2,x,c): 2*x is exact, so the single rounding is the same one.
+// EXACT_DIV = false (MODE_FAST since round 5; its contract is a tolerance against the FMA path, not its bits): the quotient as
+// num * rcp(den), v_rcp_f32 being accurate to 1 ulp -- <= 1.8e-7 of a value in [-1, 1] against a per-pixel budget of 6.3e-4 --
+// instead of the correctly rounded division the bit-exact modes need (6 packed instructions per pixel pair less, 2 % of the hybrid).
+template <bool EXACT_DIV = true>
 __device__ __forceinline__ float ssim_px(float muA, float muB, float eAA, float eBB, float eAB, float c1, float c2)
 {
     const float muA2 = muA * muA, muB2 = muB * muB, muAB = muA * muB;
     const float sA2 = eAA - muA2, sB2 = eBB - muB2, sAB = eAB - muAB;
     const float num = __builtin_fmaf(2.0f, muAB, c1) * __builtin_fmaf(2.0f, sAB, c2);
     const float den = ((muA2 + muB2) + c1) * ((sA2 + sB2) + c2);
-    return num / den;
+    if constexpr (EXACT_DIV) return num / den;
+    else                     return num * __builtin_amdgcn_rcpf(den);
 }
 __device__ __forceinline__ double ssim_px(double muA, double muB, double eAA, double eBB, double eAB, double c1, double c2)
 {
@@ -285,6 +290,7 @@ __device__ __forceinline__ f2 div_inrange_finish(f2 n, f2 d, f2 r)
 // everything that does not involve E[ab] -- the denominator and its refined reciprocal -- is issued together
 // with the ab stream's blur (independent work to hide the dependent chain behind), the rest after it.
 struct Px2 { f2 muAB, den, rcp; };
+template <bool EXACT_DIV = true>
 __device__ __forceinline__ Px2 ssim_px2_head(f2 mu0, f2 mu1, f2 e0, f2 e1, float c1, float c2)
 {
     const f2 m0 = mu0 * mu0, m1 = mu1 * mu1;             // (muA^2, muB^2) per column
@@ -296,15 +302,18 @@ __device__ __forceinline__ Px2 ssim_px2_head(f2 mu0, f2 mu1, f2 e0, f2 e1, float
     const f2 C1 = {c1, c1}, C2 = {c2, c2};
     const f2 tm = {opaque(m0.x + m0.y), opaque(m1.x + m1.y)}, ts = {opaque(s0.x + s0.y), opaque(s1.x + s1.y)};
     h.den = (tm + C1) * (ts + C2);
-    h.rcp = div_inrange_rcp(h.den);
+    if constexpr (EXACT_DIV) h.rcp = div_inrange_rcp(h.den);
+    else                     h.rcp = f2{__builtin_amdgcn_rcpf(h.den.x), __builtin_amdgcn_rcpf(h.den.y)};      // see ssim_px
     return h;
 }
+template <bool EXACT_DIV = true>
 __device__ __forceinline__ f2 ssim_px2_tail(const Px2& h, f2 eAB, float c1, float c2)
 {
     const f2 two = {2.0f, 2.0f}, C1 = {c1, c1}, C2 = {c2, c2};
     const f2 sAB = eAB - h.muAB;
     const f2 n = fma_(two, h.muAB, C1) * fma_(two, sAB, C2);
-    return div_inrange_finish(n, h.den, h.rcp);
+    if constexpr (EXACT_DIV) return div_inrange_finish(n, h.den, h.rcp);
+    else                     return n * h.rcp;
 }
 
 // MODE_SEPARABLE and MODE_DOUBLE work on FOUR blurred planes, not five: the SSIM formula needs the two variances only as
@@ -906,7 +915,7 @@ void ssim_strip2_kernel(const KArgs args)
             // (6) the ab stream
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (phase != ROW_WARMUP)
-                head = ssim_px2_head(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
+                head = ssim_px2_head<!HYB>(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
             // ab plane: both columns packed, xx[k] = (ab[k], ab[k+1]); the centre pair is index 5
             const f2 x1 = wxx[6] + wxx[4], x2 = wxx[7] + wxx[3], x3 = wxx[8] + wxx[2], x4 = wxx[9] + wxx[1], x5 = wxx[10] + wxx[0];
             blur_exact<FUSED, KMIN>(accX, wxx[5], x1, x2, x3, x4, x5);
@@ -922,7 +931,7 @@ void ssim_strip2_kernel(const KArgs args)
         if constexpr (phase != ROW_WARMUP) {
             f2 v;
             if constexpr (FAST) v = ssim_px2_sep(accAB[0][0], accAB[1][0], accQ[0][0], accQ[1][0], args.c1, args.c2);
-            else                v = ssim_px2_tail(head, accX[0], args.c1, args.c2);
+            else                v = ssim_px2_tail<!HYB>(head, accX[0], args.c1, args.c2);
             colsum[0] += (double)v.x;               // fp64 accumulation, src/ssim_avx.cpp:357-358
             colsum[1] += (double)v.y;
             if constexpr (MAP != 0) {
@@ -1210,7 +1219,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
                 colsum += (double)v;
                 vmap = v;
             } else {
-                const float v = ssim_px(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1, args.c2);
+                const float v = ssim_px<!HYB>(accAB[0].x, accAB[0].y, accQ[0].x, accQ[0].y, accX[0], args.c1, args.c2);
                 colsum += (double)v;
                 vmap = v;
             }

@@ -74,11 +74,10 @@ def test_fast_modes_full_size_4k(gpu_ctx, oracle, mode):
 @pytest.mark.parametrize("mode", [ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE])
 def test_fast_modes_reproduce_the_cpu_model_of_their_arithmetic(gpu_ctx, oracle, mode):
     """tests/tools/fast_mode_model.py restates both modes' arithmetic in numpy (that model is what DESIGN.md's tables and
-    margins come from).  The kernels -- both variants -- must produce the model's per-pixel bits: on noise, on natural
-    fixtures, and on the division's corner statistics (anti-correlated textures whose covariance sweeps 2*sAB + c2 through
-    zero, flat, saturated and maximal-contrast images: the in-range division of the packed epilogues against numpy's IEEE
-    one).  The model emulates fma through float64, which double-rounds once in ~1e8 operations: at most 3 pixels per image
-    may differ, by one ulp."""
+    margins come from).  The kernels -- both variants -- must produce the model's per-pixel values to 3 ulp (rounds 3-4: its bits; since
+    round 5 both modes divide as n * rcp(d), which numpy cannot reproduce) and each other's bits: on noise, on natural fixtures, and on
+    the division's corner statistics (anti-correlated textures whose covariance sweeps 2*sAB + c2 through zero, flat, saturated and
+    maximal-contrast images)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import fast_mode_model as model
@@ -103,23 +102,19 @@ def test_fast_modes_reproduce_the_cpu_model_of_their_arithmetic(gpu_ctx, oracle,
     wants = [fn(a, b) for (a, b) in cases]
     maps = {}
     try:
-        # variant 0: the default two-column kernel (MODE_SEPARABLE, unit steps: the pair-staging kernel ssim_sep2_kernel);
-        # 1: one column per lane; 2: the byte-load two-column kernel (the same as 0 for MODE_FAST)
+        # variant 0: the default two-column kernel; 1: one column per lane; 2: the two-column kernel forced (the same as 0 here)
         for variant in (0, 1, 2):
             gpu_ctx.set_tuning(0, variant)
             for i, (a, b) in enumerate(cases):
                 want = wants[i]
                 v, m = gpu_ctx.ssim_planes(a, b, want_map=True)
                 ulps = np.abs(m.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
-                if mode == ssim_amd.MODE_FAST:
-                    assert int((ulps != 0).sum()) <= 3 and int(ulps.max()) <= 1, (mode, variant, i, int((ulps != 0).sum()), int(ulps.max()))
-                else:
-                    # round 5: MODE_SEPARABLE's quotient is n * rcp(d) with the hardware's 1-ulp reciprocal (the model divides
-                    # exactly): <= 3 ulp of any pixel, and the three kernels -- same operations, same v_rcp_f32 -- agree bit for bit
-                    assert int(ulps.max()) <= 3, (mode, variant, i, int(ulps.max()))
-                    assert np.array_equal(m.view(np.uint32), maps.setdefault(i, m).view(np.uint32)), (variant, i)
+                # round 5: both modes form their quotient as n * rcp(d) with the hardware's 1-ulp reciprocal (the model divides exactly):
+                # <= 3 ulp of any pixel from the model, and the kernels of a mode -- same operations, same v_rcp_f32 -- agree bit for bit
+                assert int(ulps.max()) <= 3, (mode, variant, i, int(ulps.max()))
+                assert np.array_equal(m.view(np.uint32), maps.setdefault(i, m).view(np.uint32)), (variant, i)
                 g = np.float32(want.astype(np.float64).sum() / np.float64(want.size))
-                assert abs(float(v) - float(g)) <= 1.3e-7 + (2e-7 if mode == ssim_amd.MODE_SEPARABLE else 0.0), (mode, variant, i)
+                assert abs(float(v) - float(g)) <= 1.3e-7 + 2e-7, (mode, variant, i)
     finally:
         gpu_ctx.set_tuning(0, 0)
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
