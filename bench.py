@@ -279,12 +279,12 @@ def attainable_hbm_gbs(torch, dev):
 def kernel_name(mode, variant, want_map, plan=None):
     """Template instance rocprofv3 lists for this configuration (ssim_kernels.hip): the two-column kernel's second argument
     is 0 = no map, 2 = map with 8-byte stores (bench maps are dense, widths even), its third whether the bit-exact modes run their
-    EARLY form (short launches), its fourth the balanced schedule (bit-exact modes, no map; both from rmgr_ssim_hip_get_plan:
+    EARLY form (short launches), its fourth the balanced schedule (bit-exact modes and MODE_FAST, no map; both from rmgr_ssim_hip_get_plan:
     `plan`); the one-column kernel's are bools (map, 64-bit addressing)."""
     if mode == 2 or variant == 1:
         return "ssim_strip1_kernel<%d, %s, false>" % (mode, "true" if want_map else "false")     # last argument: 64-bit addressing (never needed by the bench's pairs)
-    balanced = bool(plan is not None and plan.balancedChunks and not want_map and mode in (0, 3))
-    early = balanced or bool(plan is not None and plan.earlyRowSums)
+    balanced = bool(plan is not None and plan.balancedChunks and not want_map and mode in (0, 3, 1))
+    early = (balanced and mode != 1) or bool(plan is not None and plan.earlyRowSums)
     return "ssim_strip2_kernel<%d, %d, %s, %s>" % (mode, 2 if want_map else 0, "true" if early else "false", "true" if balanced else "false")
 
 
@@ -659,6 +659,7 @@ def main():
     if args.mode == 0 and rank == 0 and mine:
         for key, m in (("fast_mode", 1), ("separable_mode", 4)):
             ctx.set_mode(m)
+            plan_m = ssim_amd.get_plan(W, H, mine, ctx)
             for _ in range(2):
                 ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
             ctx.synchronize()
@@ -670,7 +671,7 @@ def main():
             ctx.set_profiling(False)
             ctx.set_mode(0)
             roof_f, valu_f = figures(m, mine, W, H, want_map, ms_f / n_f)
-            other[key] = {"mode": MODE_NAMES[m], "kernel": kernel_name(m, args.variant, want_map),
+            other[key] = {"mode": MODE_NAMES[m], "kernel": kernel_name(m, args.variant, want_map, plan_m),
                           "kernel_avg_ms": round(ms_f / n_f, 4), "mpix_s": round(float(mine) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1),
                           "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"], "ops_per_pixel": valu_f["ops_per_pixel"]}
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)

@@ -113,7 +113,7 @@ typedef struct rmgr_ssim_hip_Plan
     rmgr_uint32_t earlyRowSums;      /* 1: the bit-exact two-column kernel runs in its EARLY form (launches of <= 3 x waveSlots wavefronts) */
     rmgr_uint32_t cellRows;          /* rows of a reduction cell (64 columns x cellRows rows): 8, or 32 for images of >= 2048 rows */
     rmgr_uint32_t cellsX, cellsY;    /* the image's grid of reduction cells: cellsX * cellsY fp64 partials per image (rmgr_ssim_hip_enqueue_rows) */
-    rmgr_uint32_t balancedChunks;    /* > 0: a launch of these pairs WITHOUT a map runs the balanced schedule of the bit-exact two-column kernel -- this many */
+    rmgr_uint32_t balancedChunks;    /* > 0: a launch of these pairs WITHOUT a map runs the balanced schedule of the two-column kernel (modes 0, 3, 1) -- this many */
     rmgr_uint32_t balancedChunkRows; /*      wavefronts, each walking this many rows of the launch's flattened [image][strip column][row] list -- instead of */
                                      /*      the strips above (same results bit for bit; scheduling only); 0: the strips */
 } rmgr_ssim_hip_Plan;

@@ -659,7 +659,7 @@ enum { ROW_WARMUP = 0, ROW_MAIN = 1, ROW_LAST = 2 };
 // the fold at the bottom of the previous iteration, in the wave's low-priority phase, and cross the loop edge instead of
 // the folded sums (24 registers either way); the high-priority phase then only scatters them into the ring.  Same
 // operations, same bits.  It pays on launches of few rounds of wave slots and costs on long ones (see launch()).
-// BAL (bit-exact modes without a map, with EARLY): the balanced schedule (work_setup above) -- the body below in a segment loop.
+// BAL (no map; bit-exact modes with EARLY, and MODE_FAST): the balanced schedule (work_setup above) -- the body below in a segment loop.
 template <int MODE, int MAP, bool EARLY = false, bool BAL = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == MODE_SEPARABLE ? 3 : 2, MODE == MODE_SEPARABLE ? 3 : 2)))
 void ssim_strip2_kernel(const KArgs args)
@@ -1322,11 +1322,14 @@ template <int MODE>
 hipError_t launch_strip2(const Geometry& geo, const KArgs& ka, bool map, hipStream_t stream, bool early)
 {
     const dim3 grid(geo.strips_x, geo.strips_y, geo.count), block(64);
-    if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
-        if (geo.chunk_cells != 0 && !map) {          // the balanced schedule (plan()): bit-exact modes, no map, EARLY row sums
-            hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, true, true>), dim3(geo.n_chunks, 1, 1), block, 0, stream, ka);
+    if constexpr (MODE != MODE_SEPARABLE) {
+        if (geo.chunk_cells != 0 && !map) {          // the balanced schedule (plan()): no map; the bit-exact modes with EARLY row sums
+            constexpr bool EARLY = (MODE == MODE_EXACT || MODE == MODE_UNFUSED);
+            hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, EARLY, true>), dim3(geo.n_chunks, 1, 1), block, 0, stream, ka);
             return hipGetLastError();
         }
+    }
+    if constexpr (MODE == MODE_EXACT || MODE == MODE_UNFUSED) {
         if (early) {
             if (!map)              hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 0, true>), grid, block, 0, stream, ka);
             else if (geo.map_unit) hipLaunchKernelGGL((ssim_strip2_kernel<MODE, 2, true>), grid, block, 0, stream, ka);
@@ -1550,15 +1553,17 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries
     g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
-    // The balanced schedule (work_setup()): the bit-exact two-column kernel without a map (launch_strip2() checks the map).  Tuning
+    // The balanced schedule (work_setup()): the two-waves-per-SIMD two-column kernels (bit-exact modes, MODE_FAST) without a map (launch_strip2() checks the map).  Tuning
     // variant 6 forces it.  By default it is taken where the packing model prices the strips at least 7 % above one round of equal
     // chunks AND a chunk is at most 1100 rows: measured with strips and chunks interleaved on one box over 32 launch shapes
     // (profiles/r05_balanced_sweep.txt), the chunks run ~5.5 % slower than this model says (a static equal partition needs every
     // SIMD to run at the same speed for the whole launch; the strips' later rounds absorb the differences), more for long chunks:
     // the rule picks 24 / 40 / 48 / 64 / 96 / 128 x 1080p (+4.0 / +5.2 / +5.7 / +4.0 / +1.2 / +2.1 %) and 3 x 4096^2 (+4.8 %), and leaves
     // alone everything the chunks lose on (8 x 1080p -7 %, 12 / 24 x 4096^2 -3 / -5 %, 192...384 x 1080p -2...-3.5 %) or only tie.
+    // MODE_FAST, same rule, same shapes: +5.1 / +5.4 / +6.6 / +3.8 / +5.5 / +3.4 % and +5.1 %.  MODE_SEPARABLE (three waves per SIMD) LOSES with chunks
+    // nearly everywhere (-1...-17 %; at best +2 %): it keeps its strips and has no balanced instantiation.
     g.chunk_cells = 0; g.n_chunks = 0;
-    if ((mode == MODE_EXACT || mode == MODE_UNFUSED) && g.strip_w == 128 && rows_total > 0 && (variant == 6 || (variant == 0 && default_rows))) {
+    if ((mode == MODE_EXACT || mode == MODE_UNFUSED || mode == MODE_FAST) && g.strip_w == 128 && rows_total > 0 && (variant == 6 || (variant == 0 && default_rows))) {
         const uint64_t col_cells = (rows_total + cr - 1) / cr, all = (uint64_t)count * g.strips_x * col_cells;
         const uint64_t want = g.wave_slots;
         if (all > want && all < (1ull << 31)) {

@@ -188,10 +188,11 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
 @pytest.mark.parametrize("shape", [(640, 360, 120), (130, 2049, 20), (1920, 1080, 24), (257, 65, 700)],
                          ids=["8-row-cells", "32-row-cells-short-last", "default-rule-1080p", "many-small"])
 def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
-    """Round 5: the balanced schedule of the bit-exact two-column kernel (launches without a map: one round of equal chunks of the
-    flattened [image][strip column][cell row] list, wavefronts continuing into the next strip column or image) must give the strips'
+    """Round 5: the balanced schedule of the two-waves-per-SIMD two-column kernels (launches without a map: one round of equal chunks of
+    the flattened [image][strip column][cell row] list, wavefronts continuing into the next strip column or image) must give the strips'
     per-image fp64 sums bit for bit -- forced (tuning variant 6) and as plan()'s default choice -- on hostile values, in both
-    bit-exact modes, for chunk boundaries inside images, at image ends and with short last cells."""
+    bit-exact modes and MODE_FAST, for chunk boundaries inside images, at image ends and with short last cells.  MODE_SEPARABLE has
+    no balanced form (it loses with it: profiles/r05_balanced_sweep_modes.txt): variant 6 there runs the strips."""
     w, h, n = shape
     rng = np.random.default_rng(w * 7 + h + n)
     base = hostile_pairs(rng, w, h, 6)
@@ -208,13 +209,14 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
             params[i] = ssim_amd.make_params(w, h, planes[id(a)].ptr, 1, w, planes[id(b)].ptr, 1, w)
         sums = gpu_ctx.alloc(8 * n)
         keep.append(sums)
-        for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED):
+        for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED, ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE):
             gpu_ctx.set_mode(mode)
             res = {}
             for variant, rows in ((2, 0), (3, 0), (6, 0), (0, 0), (6, 64), (2, 8)):
                 gpu_ctx.set_tuning(rows, variant)
                 if variant == 6:
-                    assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0, "the shape is meant to engage the balanced schedule"
+                    chunks = ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks
+                    assert (chunks == 0) if mode == ssim_amd.MODE_SEPARABLE else (chunks > 0), "the shape is meant to engage the balanced schedule"
                 sums.upload(np.zeros(n))
                 gpu_ctx.enqueue_batch(params, n, sums.ptr)
                 gpu_ctx.synchronize()
@@ -223,7 +225,9 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
                 assert np.array_equal(got, res[(2, 0)]), (mode, key, int((got != res[(2, 0)]).sum()))
         gpu_ctx.set_tuning(0, 0)
         if shape == (1920, 1080, 24):
-            assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0        # plan()'s default for this shape (on a 256-CU device)
+            for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_FAST):
+                gpu_ctx.set_mode(mode)
+                assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0    # plan()'s default for this shape (on a 256-CU device)
     finally:
         gpu_ctx.set_tuning(0, 0)
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)

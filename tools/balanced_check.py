@@ -1,5 +1,5 @@
 """The balanced schedule (tuning variant 6) against the strips (variants 2, 3): per-image fp64 sums of batches without a map, bit for bit,
-over sizes (ragged, shorter than a cell, many cells), batch sizes, both bit-exact modes and strip heights.  Run on the GPU box."""
+over sizes (ragged, shorter than a cell, many cells), batch sizes, the four fp32 modes and strip heights.  Run on the GPU box."""
 import sys, numpy as np
 sys.path.insert(0, '.')
 import ssim_amd
@@ -16,7 +16,7 @@ for (w, h, n) in [(256, 256, 1), (300, 301, 3), (1, 1, 5), (17, 5, 40), (129, 64
         keep += [da, db]
         params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, None, 1, w)
     ds = ctx.alloc(8 * n)
-    for mode in (0, 3):
+    for mode in (0, 3, 1, 4):
         ctx.set_mode(mode)
         res = {}
         for v in (2, 3, 6, 0):
