@@ -545,7 +545,10 @@ int pool_acquire(rmgr_ssim_hip_Context** out)
             (*out)->mode = g_pool.mode;
             return 0;
         }
-        if (g_pool.create_err && g_pool.all.empty()) return g_pool.create_err;      // no device: every call fails the same way, at once
+        if (g_pool.create_err && g_pool.all.empty()) {
+            if (g_pool.create_err == ENODEV) return ENODEV;                         // no usable device: every call fails the same way, at once
+            g_pool.create_err = 0;                                                  // anything else (out of memory at that moment ...) is tried again by the next call
+        }
         if ((int)g_pool.all.size() < g_pool.limit && !create_failed_here) {
             g_pool.all.push_back(NULL);                                             // reserve a slot; create outside the lock
             lk.unlock();
