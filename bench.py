@@ -469,23 +469,31 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher started a different number of ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs the MI355X: no HIP device visible (there is no CPU fallback)")
-    if local_rank >= torch.cuda.device_count():
+    # TEST MODE (never set by a launcher): SSIM_BENCH_SHARED_DEVICE=1 puts every rank on device 0 and carries the control plane and the
+    # exchange over gloo (RCCL refuses two ranks on one GPU) -- so that a 1-GPU box can run the N > 1 code path end to end (shards,
+    # per-rank diagnosis, digest comparison, the exchange, max-over-ranks timing).  The line it prints says so and is not a result.
+    shared_device = os.environ.get("SSIM_BENCH_SHARED_DEVICE") == "1"
+    dev_index = 0 if shared_device else local_rank
+    if dev_index >= torch.cuda.device_count():
         raise SystemExit("rank %d has no device: %d visible" % (local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("SSIM_BENCH_FORCE_DIST") == "1":      # the env switch lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29511))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if shared_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     # Everything (torch ops, RCCL, our launches) is ordered on one explicit non-default stream: the legacy
     # NULL stream adds implicit synchronisation to every launch.
     if os.environ.get("SSIM_BENCH_NULL_STREAM") != "1":
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     stream = torch.cuda.current_stream()
-    ctx = ssim_amd.Context(local_rank, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
+    ctx = ssim_amd.Context(dev_index, ctypes.c_void_p(stream.cuda_stream), mode=args.mode)
     ctx.set_tuning(args.strip_rows, args.variant)
 
     # --- the exchange step's carrier.  The product's own is rmgr_ssim_hip_comm_*: rank 0 creates the
@@ -579,7 +587,7 @@ def main():
         pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
     except Exception:  # noqa: BLE001
         pci = "unknown"
-    who = "device %d (pci %s, %s) pairs [%d, %d) carrier %s ranks_seen %s" % (local_rank, pci, torch.cuda.get_device_name(dev), first, last, exchange["carrier"], exchange["ranks_seen"])
+    who = "device %d (pci %s, %s) pairs [%d, %d) carrier %s ranks_seen %s" % (dev_index, pci, torch.cuda.get_device_name(dev), first, last, exchange["carrier"], exchange["ranks_seen"])
     digests_ok, rank_lines = sharding.compare_digests(dist, result_digest, who)
     if rank == 0 and (world > 1 or not digests_ok):
         for l in rank_lines:
@@ -813,6 +821,9 @@ def main():
             "configs": configs,
             "device": ctx.describe(),
         }
+        if shared_device:
+            line["test_mode"] = ("SSIM_BENCH_SHARED_DEVICE=1: all %d ranks ran on ONE GPU with gloo as the carrier -- a functional run of the N > 1 code path; "
+                                 "`value` is NOT a scaling result" % world)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_in_child()
             # the CPU figure of each BASELINE config beside its GPU line (all host threads, best run; the same image, the same arithmetic contract)

@@ -77,3 +77,29 @@ def test_native_rccl_exchange_inside_a_torch_process():
     """The same 1-rank exchange in a process that imported torch first: the library must pick up the RCCL (and HIP runtime)
     already in the process -- torch's bundled copies -- which is the configuration of `bench.py --exchange native`."""
     run_selftest("single", "--with-torch", extra=300)      # + the child's own limit for a first `import torch` on a fresh box
+
+
+def test_bench_two_ranks_on_one_device_over_gloo():
+    """bench.py's N > 1 code path end to end on the 1-GPU box: two ranks started by torch.distributed.run exactly as the driver starts
+    them, both on device 0 with gloo as the carrier (SSIM_BENCH_SHARED_DEVICE=1 -- RCCL refuses two ranks on one GPU, which `--exchange
+    auto` must survive by agreeing on torch's carrier): shards, the known-answer gate on the rank that owns the first seeds, the per-rank
+    diagnosis, equal digests of the exchanged result vector on both ranks, max-over-ranks timing, ONE JSON line from rank 0 -- marked as a
+    test-mode line.  (The same run with 4 ranks on configs[3] split strongly and with 8 ranks: profiles/r05_shared_device_ranks.txt.)"""
+    import json
+    env = dict(os.environ, SSIM_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RMGR_SSIM_HIP_COMM_TIMEOUT_S="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "3", "--sustain", "0", "--no-configs", "--no-cold-start",
+           "--no-cpu-baseline", "--exchange", "auto"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "test_mode" in line and line["value"] > 0
+    assert line["config"]["pairs_total"] == 6 and line["config"]["pairs_per_gpu"] == 3
+    ex = line["exchange"]
+    assert ex["ranks_seen"] == 2 and len(ex["per_rank"]) == 2
+    assert ex["carrier"] == "torch" and "native_error" in ex            # two ranks on one GPU: RCCL's communicator cannot come up, both ranks agree on that
+    digests = [l.rsplit("digest ", 1)[1] for l in ex["per_rank"]]
+    assert digests[0] == digests[1] == line["config"]["results_digest"]
+    assert "pairs [0, 3)" in ex["per_rank"][0] and "pairs [3, 6)" in ex["per_rank"][1]
