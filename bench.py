@@ -599,10 +599,19 @@ def main():
 
     # Clock settle (untimed, before the W warm-up steps): the chip takes tens of milliseconds of sustained load
     # to leave its idle DVFS state; a ~1 ms step measured right after the uploads reads up to 20 % slow.
+    # Every step carries a collective when there are several ranks, so the ranks must leave this loop after the SAME number of
+    # steps: each looks at its own clock, and they stop when all of them have seen the quarter second (one MIN all-reduce of a flag
+    # per four steps) -- a rank that stopped on its own clock one step before its peers would leave them in an all-reduce nobody answers.
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < 0.25:
-        step()
+    while True:
+        for _ in range(4):
+            step()
         torch.cuda.synchronize()
+        settled = time.perf_counter() - t_settle >= 0.25
+        if dist is not None:
+            settled = sharding.all_agree(dist, settled, dev)
+        if settled:
+            break
     for _ in range(args.warmup):
         step()
     fence()
