@@ -16,4 +16,9 @@ run n2_auto 2 --exchange auto
 run n2_torch 2 --exchange torch
 run n4_torch_strong_1080p 4 --exchange torch --workload 1080p --scaling strong
 run n8_torch 8 --exchange torch --pairs 4
+# the same through bench.py's own launcher (python bench.py --gpus N without torch.distributed.run around it)
+timeout 600 python3 bench.py --gpus 2 --steps 5 --warmup 1 --sustain 0 --no-configs --no-cold-start --no-cpu-baseline --pairs 4 --exchange torch > $OUT/n2_self_launch.log 2>&1
+echo "n2_self_launch rc=$?" >> $OUT/summary.txt
+grep '"metric"' $OUT/n2_self_launch.log > $OUT/n2_self_launch.json
+grep -E "^bench.py: " $OUT/n2_self_launch.log | head -4 >> $OUT/summary.txt
 cat $OUT/summary.txt
