@@ -1527,8 +1527,7 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         //   full rounds of waves x SIMDs strips cost u each; the last, partial round costs u x f(k) where k = how many
         //   waves the fullest SIMD still holds: a wave alone on its SIMD runs 1.46x (2-wave kernels) / 2.05x (3-wave
         //   kernels) faster than in a full house, two of three 1.4x faster.
-        // Candidates: every even split of the rows into 1 .. rows/cell strips of whole reduction cells, at most 512
-        // rows tall (taller measured no better, and less friendly to the L2 on 64 x 4096^2); taller wins ties.
+        // Candidates: every even split of the rows into 1 .. rows/cell strips of whole reduction cells, at most `cap` rows tall (below); taller wins ties.
         const uint64_t cus = (uint64_t)(cu_count > 0 ? cu_count : 256), simds = cus * 4;
         const int waves = waves_per_simd(mode, variant);
         // Round 5, three-wave kernels: a launch that fits ONE round is priced with what the round-5 MODE_SEPARABLE kernel measures for strips
@@ -1538,8 +1537,15 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         static const uint32_t tail2[2] = {685, 1000}, tail3[3] = {490, 715, 1000}, tail3_one_round[3] = {450, 665, 1000};      // x 1/1000
         const uint64_t slots = simds * (uint64_t)(waves >= 3 ? 3 : 2);
         uint64_t best = ~(uint64_t)0;
-        uint32_t best_rows = round_cell(rows_total < 512 ? rows_total : 512);
-        const uint32_t ny_min = (rows_total + 511) / 512, ny_max = (rows_total + cr - 1) / cr;
+        // Round 5: strips of the two-wave kernels may be up to 1024 rows tall (512 since round 2: "taller measured no better" then).  Measured on the round-5
+        // kernels, 512 / 1024 / 2048 interleaved over 36 shapes (profiles/r05_strip_cap_sweep.txt): 1024 is +1.2 % on 32 and 48 x 4096^2, +1.8 % on 8 x 8192^2
+        // (+2.1 % with the map), +0...1.8 % for MODE_FAST, nothing below -1.1 %; 2048 adds a few tenths and loses 2 % on 128 x 4096^2.  The three-wave
+        // kernels keep 512 (MODE_SEPARABLE at 1024 / 2048 rows: -3...-4 %).  The balanced schedule's rule below was calibrated against strips of at
+        // most 512 rows and keeps comparing with those (strips_cost).
+        const uint32_t cap = waves >= 3 ? 512u : 1024u;
+        uint64_t best_capped = ~(uint64_t)0;                              // the best split into strips of at most 512 rows
+        uint32_t best_rows = round_cell(rows_total < cap ? rows_total : cap);
+        const uint32_t ny_min = (rows_total + cap - 1) / cap, ny_max = (rows_total + cr - 1) / cr;
         for (uint32_t ny = ny_min; ny <= ny_max; ++ny) {
             const uint32_t rows = round_cell((rows_total + ny - 1) / ny);
             const uint32_t ny_eff = (rows_total + rows - 1) / rows;
@@ -1550,9 +1556,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
             const uint64_t last = rem == 0 ? 0 : tail[(rem - 1) / simds];
             const uint64_t cost = u * (full * 1000 + last);
             if (cost < best) { best = cost; best_rows = rows; }
+            if (rows <= 512 && cost < best_capped) best_capped = cost;
         }
         strip_rows = (int)best_rows;
-        strips_cost = best;
+        strips_cost = best_capped;
     }
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries

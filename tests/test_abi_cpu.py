@@ -320,12 +320,12 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
         assert (p.stripsY - 1) * p.stripRows < h <= p.stripsY * p.stripRows
         assert p.wavefronts == p.stripsX * p.stripsY * n
     # the discrete wave-slot model (ssim_kernels.hip plan()): 2 x 1024 SIMDs = 2048 slots for the bit-exact kernel
-    assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 512           # 8192 strips = four full rounds
+    assert ssim_amd.get_plan(4096, 4096, 32).stripRows == 1024          # 4096 strips = two full rounds (round 5: up to 1024 rows; 512 before)
     assert ssim_amd.get_plan(4096, 4096, 1).stripRows == 64             # 2048 strips: exactly one round
     p = ssim_amd.get_plan(1920, 1080, 16)
     assert (p.stripRows, p.stripsY, p.wavefronts) == (136, 8, 1920)     # one round; 9 strips per column would be 2160 = two rounds
     p = ssim_amd.get_plan(1920, 1080, 128)
-    assert p.stripRows % 8 == 0 and p.stripsY * p.stripRows >= 1080 > (p.stripsY - 1) * p.stripRows and p.stripRows <= 512
+    assert p.stripRows % 8 == 0 and p.stripsY * p.stripRows >= 1080 > (p.stripsY - 1) * p.stripRows and p.stripRows <= 1024
     assert ssim_amd.get_plan(256, 256, 1).stripWidth == 64              # tiny launches: twice as many, half as wide strips
     assert ssim_amd.get_plan(1024, 1024, 1).stripWidth == 128 and ssim_amd.get_plan(256, 256, 64).stripWidth == 128
     # strips start on the boundaries of the fp64 reduction cells: 32 rows for images of >= 2048 rows, else 8
@@ -352,7 +352,7 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     # round 5: the balanced schedule (one round of equal chunks instead of strips) is the default exactly where the strips leave a
     # partial round worth recovering (profiles/r05_balanced_sweep.txt): configs[3]'s per-GPU share yes, the headline batch no
     p = ssim_amd.get_plan(1920, 1080, 128)
-    assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (5760, 2041, 1016)
+    assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (3840, 2041, 1016)      # strips of 544 rows (reported; the launch runs the chunks)
     assert p.balancedChunks * p.balancedChunkRows >= 128 * 15 * 1080            # the chunks cover every row of every strip column
     for (w, h, n) in [(4096, 4096, 32), (4096, 4096, 1), (8192, 8192, 2), (1920, 1080, 1024), (1920, 1080, 256), (256, 256, 1)]:
         assert ssim_amd.get_plan(w, h, n).balancedChunks == 0, (w, h, n)
