@@ -1587,6 +1587,11 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
                 const uint64_t chunks_cost = (chunk * cr * col_cells + 12 * (col_cells + chunk)) * tail / col_cells;
                 take = strips_cost * 100 >= chunks_cost * 107;
             }
+            // ... and where a chunk divides the strip column evenly: no chunk straddles two columns, so the chunks ARE strips -- the tallest that fill the
+            // wave slots in ONE round, without a seam between rounds (8 ... 64 x 4096^2 +0.5 / +0.7 / +1.1 / +2.3 %, 2 ... 16 x 8192^2 +0.9 ... +2.1 %, 32 / 128 x
+            // 2048^2 +0.8 / +1.2 %; against the shipped strips on 38 shapes: +0.6 ... +2.4 %, single pairs included).  Chunks of several whole columns are left alone: 128 x 4096^2 -2.3 %, 512 x 2048^2 -3.9 %
+            // (profiles/r05_strip_cap_sweep.txt, last section).
+            if (!take && strips_cost != 0 && mode != MODE_FAST && col_cells % chunk == 0) take = true;      // MODE_FAST: -0.8 ... +1.0 %, no net gain: left on its strips
             if (take) {
                 g.chunk_cells = (uint32_t)chunk;
                 g.n_chunks = (uint32_t)n_chunks;

@@ -346,7 +346,7 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == errno.EINVAL
     buf[0] = 64                                                         # a client from the future: only what this library knows is written
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0
-    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 0 and buf[12] == 0 and all(v == 0xDEADBEEF for v in buf[13:])
+    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 2048 and buf[12] == 64 and all(v == 0xDEADBEEF for v in buf[13:])      # balancedChunks, balancedChunkRows: a single 4096^2 pair runs the chunks
     p = ssim_amd.get_plan(1920, 1080, 1)
     assert (p.cellRows, p.cellsX, p.cellsY) == (8, 30, 135)
     # round 5: the balanced schedule (one round of equal chunks instead of strips) is the default exactly where the strips leave a
@@ -354,8 +354,13 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     p = ssim_amd.get_plan(1920, 1080, 128)
     assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (3840, 2041, 1016)      # strips of 544 rows (reported; the launch runs the chunks)
     assert p.balancedChunks * p.balancedChunkRows >= 128 * 15 * 1080            # the chunks cover every row of every strip column
-    for (w, h, n) in [(4096, 4096, 32), (4096, 4096, 1), (8192, 8192, 2), (1920, 1080, 1024), (1920, 1080, 256), (256, 256, 1)]:
+    for (w, h, n) in [(4096, 4096, 24), (4096, 4096, 128), (1920, 1080, 1024), (1920, 1080, 256), (1920, 1080, 1), (256, 256, 1)]:
         assert ssim_amd.get_plan(w, h, n).balancedChunks == 0, (w, h, n)
+    # ... and where the chunk divides the strip column evenly (the chunks are then strips: the tallest that fill the wave slots in one round): the headline batch,
+    # a single 4096^2 pair, 8192^2 pairs -- +0.6 ... +2.4 % over the strips on every such shape (profiles/r05_strip_cap_sweep.txt)
+    for (w, h, n, chunks, rows) in [(4096, 4096, 32, 2048, 2048), (4096, 4096, 1, 2048, 64), (8192, 8192, 2, 2048, 512), (4096, 4096, 64, 2048, 4096), (512, 512, 16, 2048, 16)]:
+        p = ssim_amd.get_plan(w, h, n)
+        assert (p.balancedChunks, p.balancedChunkRows) == (chunks, rows), (w, h, n)
 
 
 def test_kernels_keep_two_waves_per_simd_and_never_spill():

@@ -23,16 +23,20 @@ def short(name):   # ssim_strip2_kernel<0, 0, true, true> -> <0, 0, true, true>
     return "`" + name[name.index("<"):] + "`"
 
 
-def trace_row(kernel):
+def trace_row(kernel, near_ms):
+    """(launches, average us) of the trace summary's row for `kernel` whose average is nearest to near_ms (one kernel + grid can serve several workloads)."""
+    best = (None, None)
     for line in open(os.path.join(P, "r05_final_bench_kernel_trace.md")):
         c = [x.strip() for x in line.split("|")]
         if len(c) > 7 and c[1] == kernel:
-            return int(c[5]), float(c[6])       # launches, average us
-    return None, None
+            n, avg = int(c[5]), float(c[6])
+            if best[1] is None or abs(avg / 1e3 - near_ms) < abs(best[1] / 1e3 - near_ms):
+                best = (n, avg)
+    return best
 
 
 head = d["roofline"]
-launches, avg_us = trace_row(head["kernel"])
+launches, avg_us = trace_row(head["kernel"], head["kernel_avg_ms"])
 cold = sp["cold_start"]
 rows = []
 rows.append("| 32 × 4096² (`value` **%s**, %.3f ms per step; sustained 6 s: %s) | exact | `%s` | %.3f ms | %s | %.0f (%.2f %%); measured HBM traffic %.3f GB per launch = %.3f× algorithmic | %.1f T (%.1f %%; %.1f %% of the 65.1 T two-wave ceiling) | %s best / %s median (4096², one pair); 1 thread %.0f |" % (
@@ -71,7 +75,7 @@ intro = ("`profiles/r05_final_*`: ONE `tools/collect_profiles.sh` call on one bo
          "regenerated from them on the box (stamped with the sha256 of the kernel source they ran), then the bench lines (which therefore carry\n"
          "`roofline.traffic`), the same command under `rocprofv3 --kernel-trace --stats` (`%s`: %.3f ms average over %d\n"
          "launches against %.3f ms from bench's HIP events), the exchange / host / latency probes, cold start, concurrent callers, the 30 000-case soak, the\n"
-         "full-size and balanced-schedule checks. Boxes differ by up to ±4 %% for identical binaries (`profiles/r05_box_spread.md`: the same collection on five\n"
+         "full-size and balanced-schedule checks. Boxes differ by up to ±4 %% for identical binaries (`profiles/r05_box_spread.md`: the same collection on six\n"
          "boxes); the A/B numbers in §0 are always one box. This table is generated: `tools/design_table.py`.\n\n"
          % (head["kernel"], avg_us / 1e3, launches, head["kernel_avg_ms"]))
 table = (intro + "| config | mode | kernel | kernel time | Mpix/s | algorithmic GB/s (% of 8 TB/s) | VALU lane-ops/s (% of 78.6 T) | CPU beside it (64 pinned threads, best run) |\n"

@@ -2,8 +2,8 @@
 """Condense rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
 
 usage: tools/summarize_prof.py <label> <kernel_trace.csv> [<counter_collection.csv> ...] > profiles/<label>.md
-Groups dispatches of our kernels by (kernel, grid) so that batch launches and single-pair launches
-are not averaged together, and averages each PMC counter per launch of the strip kernel.
+Groups dispatches of our kernels by (kernel, grid) -- and by duration where one grid serves different workloads -- so that batch launches and
+single-pair launches are not averaged together, and averages each PMC counter per launch of the strip kernel.
 """
 import collections
 import csv
@@ -29,7 +29,19 @@ def main():
     print("| kernel | grid (threads) | VGPRs | LDS B | launches | avg us | min us | max us |")
     print("|---|---|---|---|---|---|---|---|")
     for (short, grid, vg, lds), d in groups.items():
-        print("| %s | %s | %s | %s | %d | %.1f | %.1f | %.1f |" % (short, grid, vg, lds, len(d), sum(d) / len(d) / 1e3, min(d) / 1e3, max(d) / 1e3))
+        # The balanced form of the strip kernel is launched with one wavefront per wave slot whatever the batch, so launches of different
+        # workloads share a grid: split a group wherever its sorted durations jump by more than 2.5x (a 32-pair batch against a single pair).
+        d = sorted(d)
+        clusters, cur = [], [d[0]]
+        for x in d[1:]:
+            if x > 2.5 * cur[-1]:
+                clusters.append(cur)
+                cur = []
+            cur.append(x)
+        clusters.append(cur)
+        for c in clusters:
+            g = grid if len(clusters) == 1 else "%s (the launches of %.2f-%.2f ms)" % (grid, min(c) / 1e6, max(c) / 1e6)
+            print("| %s | %s | %s | %s | %d | %.1f | %.1f | %.1f |" % (short, g, vg, lds, len(c), sum(c) / len(c) / 1e3, min(c) / 1e3, max(c) / 1e3))
     others = collections.Counter()
     for r in rows:
         if "ssim_hip" not in r["Kernel_Name"]:
