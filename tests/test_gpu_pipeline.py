@@ -235,6 +235,49 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
             d.free()
 
 
+def test_row_bands_without_a_map_take_the_balanced_form_and_equal_the_strips(gpu_ctx):
+    """Round 5: plan() gives a launch without a map the balanced form wherever its chunks divide the strip column evenly -- row bands
+    (rmgr_ssim_hip_enqueue_rows) included: a band of 2048 rows of an 8192-column image is 64 x 64 cell rows = 2 per wave slot.  The band's
+    chunks start at the band's first row (y_begin > 0), not at the image's: cells of two bands under the default tuning (chunks) must be the
+    cells of the forced strips (tuning variant 2), bit for bit, and add up to the whole image's."""
+    w, h = 8192, 4096
+    rng = np.random.default_rng(8192)
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    b = np.clip(a.astype(np.int32) + rng.integers(-60, 61, (h, w)), 0, 255).astype(np.uint8)
+    keep = []
+    try:
+        da, db = gpu_ctx.upload(a), gpu_ctx.upload(b)
+        keep += [da, db]
+        p = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w)                 # no map
+        plan = ssim_amd.get_plan(w, h, 1, gpu_ctx)
+        ncell = plan.cellsX * plan.cellsY
+        assert plan.balancedChunks > 0 and plan.cellRows == 32
+        got = {}
+        for variant in (0, 2):
+            gpu_ctx.set_tuning(0, variant)
+            parts = []
+            for (y0, rows) in ((0, 2048), (2048, 2048)):
+                cells = gpu_ctx.alloc(8 * ncell).upload(np.zeros(ncell, np.float64))
+                keep.append(cells)
+                gpu_ctx.enqueue_rows(p, y0, rows, cells.ptr)
+                gpu_ctx.synchronize()
+                parts.append(cells.download(np.float64, (ncell,)))
+            assert not parts[0][ncell // 2:].any() and not parts[1][:ncell // 2].any()      # each band wrote its own cell rows only
+            got[variant] = parts
+        for k in (0, 1):
+            assert np.array_equal(bits64(got[0][k]), bits64(got[2][k])), "band %d: chunks and strips disagree in %d cells" % (k, int((bits64(got[0][k]) != bits64(got[2][k])).sum()))
+        gpu_ctx.set_tuning(0, 0)
+        whole = gpu_ctx.alloc(8 * ncell).upload(np.zeros(ncell, np.float64))
+        keep.append(whole)
+        gpu_ctx.enqueue_rows(p, 0, h, whole.ptr)
+        gpu_ctx.synchronize()
+        assert np.array_equal(bits64(whole.download(np.float64, (ncell,))), bits64(got[0][0] + got[0][1]))
+    finally:
+        gpu_ctx.set_tuning(0, 0)
+        for d in keep:
+            d.free()
+
+
 @pytest.mark.parametrize("size", [(1500, 1090), (2100, 2300), (4096, 4100)], ids=["8-row-cells", "32-row-cells", "two-reduce-chunks"])
 def test_row_bands_on_separate_contexts_equal_one_launch(gpu_ctx, size):
     """SURVEY.md 8(e), "single huge image across GPUs": one pair cut into row bands (rmgr_ssim_hip_enqueue_rows), every band
