@@ -185,8 +185,8 @@ def test_sums_do_not_depend_on_strips_variant_or_batch_split(gpu_ctx, mode, size
             d.free()
 
 
-@pytest.mark.parametrize("shape", [(640, 360, 120), (130, 2049, 20), (1920, 1080, 24), (257, 65, 700)],
-                         ids=["8-row-cells", "32-row-cells-short-last", "default-rule-1080p", "many-small"])
+@pytest.mark.parametrize("shape", [(640, 360, 120), (130, 2049, 20), (1920, 1080, 24), (257, 65, 700), (512, 512, 16), (2048, 2048, 3)],
+                         ids=["8-row-cells", "32-row-cells-short-last", "default-rule-1080p", "many-small", "even-chunks-8-row-cells", "even-chunks-32-row-cells"])
 def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
     """Round 5: the balanced schedule of the two-waves-per-SIMD two-column kernels (launches without a map: one round of equal chunks of
     the flattened [image][strip column][cell row] list, wavefronts continuing into the next strip column or image) must give the strips'
@@ -228,6 +228,10 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
             for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_FAST):
                 gpu_ctx.set_mode(mode)
                 assert ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0    # plan()'s default for this shape (on a 256-CU device)
+        if shape in ((512, 512, 16), (2048, 2048, 3)):      # the chunk divides the strip column evenly: the default of the bit-exact modes, not of MODE_FAST
+            for mode, taken in ((ssim_amd.MODE_EXACT, True), (ssim_amd.MODE_UNFUSED, True), (ssim_amd.MODE_FAST, False)):
+                gpu_ctx.set_mode(mode)
+                assert (ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0) == taken, mode
     finally:
         gpu_ctx.set_tuning(0, 0)
         gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
