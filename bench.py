@@ -633,6 +633,11 @@ def main():
     launches, kernel_ms = ctx.get_profile()
     kernel_avg_ms = kernel_ms / max(launches, 1)
     if dist is not None:
+        # every rank's own clock and kernel time, for the record (the number below is the MAX over ranks: one slow GPU sets it, and this says which)
+        mine_ms = [None] * world
+        dist.all_gather_object(mine_ms, (rank, round(elapsed / args.steps * 1e3, 4), round(kernel_avg_ms, 4)))
+        mine_ms.sort()
+        exchange["per_rank_ms"] = [{"rank": r, "ms_per_step": e, "kernel_avg_ms": k} for r, e, k in mine_ms]
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -137,3 +137,5 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     digests = [l.rsplit("digest ", 1)[1] for l in ex["per_rank"]]
     assert digests[0] == digests[1] == line["config"]["results_digest"]
     assert "pairs [0, 3)" in ex["per_rank"][0] and "pairs [3, 6)" in ex["per_rank"][1]
+    assert [r["rank"] for r in ex["per_rank_ms"]] == [0, 1] and all(r["kernel_avg_ms"] > 0 and r["ms_per_step"] >= r["kernel_avg_ms"] for r in ex["per_rank_ms"])
+    assert line["ms_per_step"] >= max(r["ms_per_step"] for r in ex["per_rank_ms"]) - 1e-3          # the line reports the slowest rank
