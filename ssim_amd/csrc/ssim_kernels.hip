@@ -1565,8 +1565,10 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries
     g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
     // The balanced schedule (work_setup()): the two-waves-per-SIMD two-column kernels (bit-exact modes, MODE_FAST) without a map (launch_strip2() checks the map).  Tuning
-    // variant 6 forces it.  By default it is taken where the packing model prices the strips at least 7 % above one round of equal
-    // chunks AND a chunk is at most 1100 rows: measured with strips and chunks interleaved on one box over 32 launch shapes
+    // variant 6 forces it.  By default it is taken where the packing model prices the strips at least 3.5 % above one round of equal
+    // chunks, a chunk is at most 1100 rows and no longer than a strip column.  (3.5 %: re-fitted late in round 5 on 128 more launch shapes -- 480p ... 8K, odd
+    // sizes, tools/r5_rule_sweep.sh + r5_rule_fit.py, profiles/r05_rule_sweep.txt: between 3.5 and 7 % the chunks gain +1 ... +4 %, e.g. 8 / 12 / 16 x 2160p, 32 x 1080p,
+    // 16 x 5K; below 3.5 % they lose as often as they win; beyond 1100 rows or one column they lose.  The first calibration, at 7 %:)  Measured with strips and chunks interleaved on one box over 32 launch shapes
     // (profiles/r05_balanced_sweep.txt), the chunks run ~5.5 % slower than this model says (a static equal partition needs every
     // SIMD to run at the same speed for the whole launch; the strips' later rounds absorb the differences), more for long chunks:
     // the rule picks 24 / 40 / 48 / 64 / 96 / 128 x 1080p (+4.0 / +5.2 / +5.7 / +4.0 / +1.2 / +2.1 %) and 3 x 4096^2 (+4.8 %), and leaves
@@ -1580,12 +1582,12 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         if (all > want && all < (1ull << 31)) {
             const uint64_t chunk = (all + want - 1) / want, n_chunks = (all + chunk - 1) / chunk;
             bool take = variant == 6;
-            if (!take && strips_cost != 0 && chunk * cr <= 1100) {
+            if (!take && strips_cost != 0 && chunk * cr <= 1100 && chunk <= col_cells) {
                 // one round of n_chunks <= wave slots chunks of chunk x cell rows, + 12 row-times per segment (1 + chunk / col_cells of them)
                 const uint64_t simds = (uint64_t)(cu_count > 0 ? cu_count : 256) * 4;
                 const uint64_t tail = n_chunks > simds ? 1000 : 685;
                 const uint64_t chunks_cost = (chunk * cr * col_cells + 12 * (col_cells + chunk)) * tail / col_cells;
-                take = strips_cost * 100 >= chunks_cost * 107;
+                take = strips_cost * 1000 >= chunks_cost * 1035;
             }
             // ... and where a chunk divides the strip column evenly: no chunk straddles two columns, so the chunks ARE strips -- the tallest that fill the
             // wave slots in ONE round, without a seam between rounds (8 ... 64 x 4096^2 +0.5 / +0.7 / +1.1 / +2.3 %, 2 ... 16 x 8192^2 +0.9 ... +2.1 %, 32 / 128 x

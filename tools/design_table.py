@@ -75,7 +75,7 @@ intro = ("`profiles/r05_final_*`: ONE `tools/collect_profiles.sh` call on one bo
          "regenerated from them on the box (stamped with the sha256 of the kernel source they ran), then the bench lines (which therefore carry\n"
          "`roofline.traffic`), the same command under `rocprofv3 --kernel-trace --stats` (`%s`: %.3f ms average over %d\n"
          "launches against %.3f ms from bench's HIP events), the exchange / host / latency probes, cold start, concurrent callers, the 30 000-case soak, the\n"
-         "full-size and balanced-schedule checks. Boxes differ by up to ±4 %% for identical binaries (`profiles/r05_box_spread.md`: the same collection on six\n"
+         "full-size and balanced-schedule checks. Boxes differ by up to ±4 %% for identical binaries (`profiles/r05_box_spread.md`: the same collection on seven\n"
          "boxes); the A/B numbers in §0 are always one box. This table is generated: `tools/design_table.py`.\n\n"
          % (head["kernel"], avg_us / 1e3, launches, head["kernel_avg_ms"]))
 table = (intro + "| config | mode | kernel | kernel time | Mpix/s | algorithmic GB/s (% of 8 TB/s) | VALU lane-ops/s (% of 78.6 T) | CPU beside it (64 pinned threads, best run) |\n"
