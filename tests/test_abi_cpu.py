@@ -539,3 +539,40 @@ def test_comm_entry_points_without_a_device(lib):
         t = time.time()
         rc = lib.rmgr_ssim_hip_comm_get_unique_id(ctypes.create_string_buffer(128))
         assert rc in (errno.ECHILD, errno.ENODEV, errno.ENOSYS, errno.ETIMEDOUT) and time.time() - t < 40, rc
+
+
+def test_plan_invariants_over_random_shapes():
+    """rmgr_ssim_hip_get_plan on 3000 random launch shapes (pure host arithmetic): the strips tile the image, start on reduction-cell boundaries and are at most 1024
+    rows tall; a balanced plan's chunks cover every cell row of every strip column exactly once in at most waveSlots wavefronts, and obey the rule they were chosen
+    by (the chunk divides the strip column evenly, or it is at most 1100 rows and no longer than a column)."""
+    import random
+    import ssim_amd
+    rnd = random.Random(20261007)
+    taken = even = 0
+    for i in range(3000):
+        kind = rnd.randrange(3)
+        if kind == 0:
+            w, h = 2 ** rnd.randrange(5, 14), 2 ** rnd.randrange(5, 14)
+        elif kind == 1:
+            w, h = rnd.choice([(640, 480), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (5120, 2880), (7680, 4320), (1600, 1200), (4096, 2160)])
+        else:
+            w, h = rnd.randrange(1, 9000), rnd.randrange(1, 9000)
+        n = rnd.choice([1, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, 256, 1024])
+        p = ssim_amd.get_plan(w, h, n)
+        cr = p.cellRows
+        assert cr == (32 if h >= 2048 else 8) and p.cellsX == (w + 63) // 64 and p.cellsY == (h + cr - 1) // cr
+        assert p.stripWidth in (64, 128) and 1 <= p.stripRows <= max(1024, cr) and p.stripRows % cr == 0
+        assert (p.stripsX - 1) * p.stripWidth < w <= p.stripsX * p.stripWidth and (p.stripsY - 1) * p.stripRows < h <= p.stripsY * p.stripRows
+        assert p.wavefronts == p.stripsX * p.stripsY * n and p.waveSlots in (2048, 3072, 4096)
+        if p.balancedChunks:
+            taken += 1
+            assert p.stripWidth == 128 and p.balancedChunkRows % cr == 0
+            col_cells, chunk = p.cellsY, p.balancedChunkRows // cr
+            cells = n * p.stripsX * col_cells
+            assert cells > p.waveSlots and p.balancedChunks <= p.waveSlots
+            assert (p.balancedChunks - 1) * chunk < cells <= p.balancedChunks * chunk          # every cell row of every strip column, once
+            if col_cells % chunk == 0:
+                even += 1
+            else:
+                assert p.balancedChunkRows <= 1100 and chunk <= col_cells, (w, h, n, p.balancedChunkRows)
+    assert taken > 300 and even > 100, (taken, even)           # the draw does exercise both ways into the balanced form
