@@ -239,6 +239,56 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
             d.free()
 
 
+def test_default_plan_equals_the_plain_strips_on_random_shapes(gpu_ctx):
+    """Whatever plan() decides for a launch without a map -- strips of any height, EARLY or not, the balanced form by either of its rules -- is scheduling only: the per-image
+    fp64 sums of the default tuning must be the bits of the plain strips (tuning variant 2, 64-row strips) on 24 random launch shapes (power-of-two sizes, video sizes, ragged
+    ones; 1 ... 96 pairs), in the bit-exact modes and MODE_FAST."""
+    rng = np.random.default_rng(20261007)
+    shapes = []
+    for i in range(24):
+        kind = i % 3
+        if kind == 0:
+            w, h = int(2 ** rng.integers(6, 12)), int(2 ** rng.integers(6, 12))
+        elif kind == 1:
+            w, h = [(640, 480), (1280, 720), (1920, 1080), (2560, 1440), (1600, 1200)][int(rng.integers(0, 5))]
+        else:
+            w, h = int(rng.integers(1, 1800)), int(rng.integers(1, 2400))
+        n = int(rng.choice([1, 2, 3, 5, 8, 13, 24, 40, 64, 96]))
+        if w * h * n <= 1 << 26:
+            shapes.append((w, h, n))
+    balanced = 0
+    for (w, h, n) in shapes:
+        base = hostile_pairs(rng, w, h, 2)
+        keep = []
+        try:
+            planes = [gpu_ctx.upload(x) for pair in base for x in pair]
+            keep += planes
+            params = (ssim_amd.Params * n)()
+            for i in range(n):
+                a, b = planes[2 * (i % 2)], planes[2 * (i % 2) + 1] if i % 3 else planes[(2 * (i % 2) + 3) % 4]
+                params[i] = ssim_amd.make_params(w, h, a.ptr, 1, w, b.ptr, 1, w)
+            sums = gpu_ctx.alloc(8 * n)
+            keep.append(sums)
+            for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED, ssim_amd.MODE_FAST):
+                gpu_ctx.set_mode(mode)
+                got = {}
+                for variant, rows in ((0, 0), (2, 64)):
+                    gpu_ctx.set_tuning(rows, variant)
+                    sums.upload(np.zeros(n))
+                    gpu_ctx.enqueue_batch(params, n, sums.ptr)
+                    gpu_ctx.synchronize()
+                    got[variant] = bits64(sums.download(np.float64, (n,)))
+                assert np.array_equal(got[0], got[2]), (w, h, n, mode, int((got[0] != got[2]).sum()))
+                gpu_ctx.set_tuning(0, 0)
+                balanced += ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks > 0
+        finally:
+            gpu_ctx.set_tuning(0, 0)
+            gpu_ctx.set_mode(ssim_amd.MODE_EXACT)
+            for d in keep:
+                d.free()
+    assert balanced >= 6, balanced            # the draw reaches the balanced form
+
+
 def test_row_bands_without_a_map_take_the_balanced_form_and_equal_the_strips(gpu_ctx):
     """Round 5: plan() gives a launch without a map the balanced form wherever its chunks divide the strip column evenly -- row bands
     (rmgr_ssim_hip_enqueue_rows) included: a band of 2048 rows of an 8192-column image is 64 x 64 cell rows = 2 per wave slot.  The band's
