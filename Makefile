@@ -29,7 +29,7 @@ lib: $(OUT)/librmgr-ssim-hip.so $(OUT)/librmgr-ssim-hip-double.so $(OUT)/librmgr
 # a group of the same signature (anything using std::make_shared, std::thread, ...) makes the final link discard the
 # archive's copy and leaves its now-local references dangling ("defined in discarded section").  Allocated into ordinary
 # sections here, the archive's copies are private to it and always kept.
-$(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
+$(OUT)/librmgr-ssim.a: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_probe.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o
 	@mkdir -p $(OUT)
 	ld -r --force-group-allocation -o $(OBJ)/rmgr_ssim_api.o $^
 	objcopy --wildcard --keep-global-symbol='rmgr_ssim_*' --keep-global-symbol='_ZN4rmgr4ssim12compute_ssimE*' --keep-global-symbol='_ZN4rmgr4ssim11select_implE*' $(OBJ)/rmgr_ssim_api.o
@@ -52,6 +52,11 @@ $(OBJ)/ssim_kernels.o: $(SRC)/ssim_kernels.hip $(SRC)/ssim_kernels.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DSSIM_KERNELS_SOURCE_ID=\"$$(sha256sum $< | cut -c1-64)\" -c $< -o $@
 
+# The forced-occupancy VALU probe behind rmgr_ssim_hip_probe_valu (profiling aid): its own file, so that the kernel source id above names the SSIM kernels only.
+$(OBJ)/ssim_probe.o: $(SRC)/ssim_probe.hip $(SRC)/ssim_kernels.h
+	@mkdir -p $(OBJ)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
 $(OBJ)/ssim_hip_abi.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h include/rmgr/ssim-hip.h include/rmgr/ssim.h
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
@@ -64,7 +69,7 @@ $(OBJ)/ssim_dropin.o: $(SRC)/ssim_dropin.cpp $(SRC)/ssim_internal.h include/rmgr
 # Only the API leaves the shared libraries: $(SRC)/exports.map (the reference's archive exposes only its API as well).
 EXPORTS := -Wl,--version-script=$(SRC)/exports.map
 
-$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
+$(OUT)/librmgr-ssim-hip.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_probe.o $(OBJ)/ssim_hip_abi.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 
@@ -76,7 +81,7 @@ $(OBJ)/ssim_hip_abi_double.o: $(SRC)/ssim_hip_abi.cpp $(SRC)/ssim_kernels.h incl
 	@mkdir -p $(OBJ)
 	$(HIPCC) $(HIPFLAGS) -DRMGR_SSIM_USE_DOUBLE=1 -x hip -c $< -o $@
 
-$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
+$(OUT)/librmgr-ssim-hip-double.so: $(OBJ)/ssim_kernels.o $(OBJ)/ssim_probe.o $(OBJ)/ssim_hip_abi_double.o $(OBJ)/ssim_dropin.o $(OBJ)/ssim_openmp.o $(SRC)/exports.map
 	@mkdir -p $(OUT)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(EXPORTS) -o $@ $(filter %.o,$^)
 

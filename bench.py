@@ -68,9 +68,12 @@ VALU_OPS_PER_PIXEL = {0: 278, 1: 220, 2: 137, 3: 278, 4: 119}
 FP64_MATH_OPS_PER_PIXEL = 88          # mode 2 only: the fp64 multiply-adds of blur + formula among those 137 slots (round 2's accounting; kept so that rounds compare)
 VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz lane-ops/s; = 157.3 TFLOP/s fp32 vector spec / 2
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
-VALU_MEASURED_PEAK_TOPS = 74.6        # best v_pk_fma_f32 rate this chip sustains: 8 waves/SIMD, tools/occupancy_probe.hip (profiles/r04_occupancy_probe.txt)
-VALU_MEASURED_2WAVE_TOPS = 65.1       # the same stream with the occupancy FORCED to the 2 waves/SIMD the kernel's 110 accumulator VGPRs allow (rounds
-                                      # 1-3 quoted 58.1 / 68.7 from tools/valu_probe.hip, whose launches did not force an even placement of the waves)
+# Rounds 4-5 divided every kernel by two CONSTANTS measured once, on one round-4 box (tools/occupancy_probe.hip: 74.6 / 65.1 T lane-ops/s at 8 / 2 waves
+# per SIMD) -- while the boxes of the pool differ by +-4 %.  Since round 6 the line carries the peak of the box it ran on: rmgr_ssim_hip_probe_valu (the
+# same forced-occupancy v_pk_fma_f32 stream, inside the library) runs in-process right before the warm-up and right after the timed steps; the
+# constants below are kept in the line for comparison with those rounds only, no fraction is computed from them any more.
+ROUND4_BOX_VALU_TOPS = {"8wave": 74.6, "2wave": 65.1, "3wave": 70.7}
+KERNEL_WAVES_PER_SIMD = {0: 2, 1: 2, 2: 3, 3: 2, 4: 3}      # what each mode's strip kernel runs at (its VGPR count; ssim_kernels.hip waves_per_simd())
 MODE_NAMES = ["exact (reference FMA order, bit-faithful)", "fast (reference-order E planes + separable mu planes; inside the FMA-relative tolerance on the reference's image sets, not a guarantee)",
               "double (fp64 internals)", "unfused (reference AVX order)", "separable (all planes separable fp32, four planes, centred; reference test tolerance vs the exact value)"]
 # tests/ssim_naive.h<double> known answers of the synthetic pairs, seeds 0x5EED, 0x5EEE, ...
@@ -326,6 +329,25 @@ class Batch(object):
             self.params[i] = ssim_amd.make_params(w, h, a.data_ptr(), 1, w, b.data_ptr(), 1, w, m.data_ptr() if want_map else None, 1, w)
 
 
+def probe_box(ctx, occupancies=(2, 8)):
+    """{waves per SIMD: T lane-ops/s} a pure v_pk_fma_f32 stream sustains on this box right now at each forced occupancy (rmgr_ssim_hip_probe_valu:
+    two untimed + five timed ~2 ms launches per occupancy, the median)."""
+    return {int(w): round(ctx.probe_valu(int(w), 0, 5), 2) for w in occupancies}
+
+
+def against_box(valu, mode, samples):
+    """Adds the box-relative fractions to a `valu` object: `samples` = probe_box() results taken around the timed launches (mean of them per occupancy)."""
+    if mode == 2:
+        return valu     # fp64 internals: its unit is fp64-rate issue slots, the packed-fp32 stream is not its yardstick
+    waves = KERNEL_WAVES_PER_SIMD[mode]
+    mean = lambda w: sum(smp[w] for smp in samples) / len(samples)
+    at_kernel, at_8 = mean(waves), mean(8)
+    valu.update({"kernel_waves_per_simd": waves, "box_peak_%dwave" % waves: round(at_kernel, 2), "box_peak_8wave": round(at_8, 2),
+                 "frac_of_box_peak_at_kernel_occupancy": round(valu["achieved"] / at_kernel, 4), "frac_of_box_peak": round(valu["achieved"] / at_8, 4),
+                 "box_peak_samples": [{"%dwave" % k: v for k, v in sorted(smp.items())} for smp in samples]})
+    return valu
+
+
 def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_map, mode, kats, steps):
     """One extra BASELINE config on this rank: KAT gate, then `steps` launches timed with HIP events on the launch stream."""
     batch = Batch(torch, ssim_amd, synth, ctx, dev, w, h, 0, pairs, want_map)
@@ -367,6 +389,8 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
         for _ in range(2):
             ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
         ctx.synchronize()
+        occ = (KERNEL_WAVES_PER_SIMD[mode], 8)
+        box = [probe_box(ctx, occ)] if mode != 2 else []
         ctx.get_profile()
         ctx.set_profiling(True)
         t0 = time.perf_counter()
@@ -376,10 +400,13 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
         wall = time.perf_counter() - t0
         ctx.set_profiling(False)
         n, ms = ctx.get_profile()
+        if mode != 2:
+            box.append(probe_box(ctx, occ))
     finally:
         ctx.set_mode(0)
     k_ms = ms / max(n, 1)
     roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
+    against_box(valu, mode, box)
     return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
             "kernel": kernel_name(mode, 0, want_map, plan), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
             "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
@@ -612,6 +639,10 @@ def main():
             settled = sharding.all_agree(dist, settled, dev)
         if settled:
             break
+    # The box's own VALU peak, right before the warm-up (clocks are settled) and again right after the timed steps: the yardstick the
+    # kernel's lane-operations per second are divided by (valu.frac_of_box_peak_at_kernel_occupancy).  Local to the rank, no collective.
+    occupancies = (2, 3, 8)
+    box_samples = [probe_box(ctx, occupancies)]
     for _ in range(args.warmup):
         step()
     fence()
@@ -632,6 +663,7 @@ def main():
         raise SystemExit("rank %d: the timed steps returned different sums than the gated step" % rank)
     launches, kernel_ms = ctx.get_profile()
     kernel_avg_ms = kernel_ms / max(launches, 1)
+    box_samples.append(probe_box(ctx, occupancies))
     if dist is not None:
         # every rank's own clock and kernel time, for the record (the number below is the MAX over ranks: one slow GPU sets it, and this says which)
         mine_ms = [None] * world
@@ -693,9 +725,11 @@ def main():
             ctx.set_profiling(False)
             ctx.set_mode(0)
             roof_f, valu_f = figures(m, mine, W, H, want_map, ms_f / n_f)
+            against_box(valu_f, m, box_samples)
             other[key] = {"mode": MODE_NAMES[m], "kernel": kernel_name(m, args.variant, want_map, plan_m),
                           "kernel_avg_ms": round(ms_f / n_f, 4), "mpix_s": round(float(mine) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1),
-                          "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"], "ops_per_pixel": valu_f["ops_per_pixel"]}
+                          "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"], "ops_per_pixel": valu_f["ops_per_pixel"],
+                          "valu_frac_of_box_peak_at_kernel_occupancy": valu_f["frac_of_box_peak_at_kernel_occupancy"], "kernel_waves_per_simd": valu_f["kernel_waves_per_simd"]}
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         ctx.synchronize()
 
@@ -809,9 +843,12 @@ def main():
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
                          "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
-            valu.update({"measured_peak": VALU_MEASURED_PEAK_TOPS, "frac_of_measured_peak": round(valu["achieved"] / VALU_MEASURED_PEAK_TOPS, 4),
-                         "measured_peak_at_kernel_occupancy": VALU_MEASURED_2WAVE_TOPS,
-                         "frac_of_peak_at_kernel_occupancy": round(valu["achieved"] / VALU_MEASURED_2WAVE_TOPS, 4)})
+            against_box(valu, args.mode, box_samples)
+            valu.update({"box_peak_2wave": round(sum(b[2] for b in box_samples) / len(box_samples), 2),
+                         "box_peak_note": "rmgr_ssim_hip_probe_valu in this process, on this box: a pure v_pk_fma_f32 stream at a FORCED occupancy of 2 / 8 waves per SIMD "
+                                          "(register footprint padded, grid = the chip's capacity), median of 5 launches of ~2 ms each, once right before the warm-up "
+                                          "steps and once right after the timed steps (box_peak_samples, in that order); the fractions divide by the mean of the two",
+                         "round4_box_constants": dict(ROUND4_BOX_VALU_TOPS, note="what rounds 4-5 divided by (one round-4 box, tools/occupancy_probe.hip); for comparison only")})
         line = {
             "metric": "Mpix/s (global SSIM, no map) on 4K pairs; achieved HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

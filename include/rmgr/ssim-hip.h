@@ -58,8 +58,11 @@ extern "C" {
  *      (ETIMEDOUT), comm_rank_count / comm_describe added; row-band entry points (enqueue_rows, reduce_cells) added
  *   5  round 5: MODE_FAST (1) and MODE_SEPARABLE (4) form their quotient as n * rcp(d): their values moved by <= 3 ulp (contracts unchanged); ctx == NULL calls
  *      run on a pool of default contexts and no longer serialise; Plan grew by balancedChunks / balancedChunkRows (harmless: structSize);
- *      the deadline of synchronize / destroy applies per queued all-reduce; get_default_pool, get_kernel_source_id added */
-#define RMGR_SSIM_HIP_ABI_VERSION 5
+ *      the deadline of synchronize / destroy applies per queued all-reduce; get_default_pool, get_kernel_source_id added
+ *   6  round 6: additions only -- probe_valu, tune / get_tuned, trim / trim_default_pool / get_default_pool_memory / get_memory_info; the default contexts
+ *      release staging above $RMGR_SSIM_HIP_POOL_RETAIN_MB when a call ends; a threadPool with a dispatch function IS called (one job per row band, ECHILD
+ *      when it fails); Plan: balancedInterleave appended (harmless: structSize), tuning variants 7 and 100 + T; set_mode / get_mode(NULL) no longer wait for a lease */
+#define RMGR_SSIM_HIP_ABI_VERSION 6
 rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT;
 
 /* sha256 (hex) of the kernel source this library's device code was compiled from ("unknown" when it was not built by the Makefile).
@@ -69,6 +72,21 @@ const char* rmgr_ssim_hip_get_kernel_source_id(void) RMGR_NOEXCEPT;
 /* The default contexts of the ctx == NULL entry points (see rmgr_ssim_hip_compute_ssim_host): how many exist right now and how many
  * calls may be in flight at a time.  Either pointer may be NULL.  Creates nothing. */
 rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t* limit) RMGR_NOEXCEPT;
+
+/* Memory policy of the default contexts.  A context's staging -- device copies of the images and the map, cell partials, descriptor tables,
+ * pinned host mirrors and bounce buffers -- is grow-only WHILE a call runs, so that a caller looping over frames of one size allocates once.  The
+ * reference keeps nothing past the call (src/ssim.cpp:1048-1088: one alloc / dealloc pair inside compute_ssim, include/rmgr/ssim.h:505-525), so:
+ *   - when a ctx == NULL call ends and its context holds more than $RMGR_SSIM_HIP_POOL_RETAIN_MB (per context, device + pinned; default 256;
+ *     0: keep nothing; negative: no cap) everything is released before the context is leased again: an 8192^2 + map call (134 MB + 268 MB of
+ *     staging) leaves nothing behind, a 4096^2 + map loop (100 MB) keeps its buffers;
+ *   - rmgr_ssim_hip_trim_default_pool() releases the staging of every default context that is not inside a call right now (the contexts themselves --
+ *     stream, events -- stay: the next call re-grows what it needs; contexts in use are skipped);
+ *   - rmgr_ssim_hip_get_default_pool_memory() reports what the default contexts held when their last call ended (device bytes, pinned host bytes)
+ *     and the cap in force (bytes; UINT64_MAX: none).  Any pointer may be NULL.  Creates nothing.
+ * rmgr_ssim_hip_trim(ctx) does the same for a caller-owned context (which has no cap: its owner decides; it must not be in use by another
+ * thread; queued work is waited for first); ctx == NULL: the default pool.  Results never depend on any of this. */
+rmgr_int32_t rmgr_ssim_hip_trim_default_pool(void) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_get_default_pool_memory(rmgr_uint64_t* deviceBytes, rmgr_uint64_t* pinnedBytes, rmgr_uint64_t* retainCapBytes) RMGR_NOEXCEPT;
 
 /* An engine instance: one device, one stream, its own grow-only scratch.  A context may be used by one
  * host thread at a time (create one per thread, or serialise); ctx == NULL entry points lease one of the
@@ -83,16 +101,26 @@ rmgr_int32_t rmgr_ssim_hip_get_device_count(rmgr_int32_t* count) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** ctx, rmgr_int32_t device, void* stream) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
 
+rmgr_int32_t rmgr_ssim_hip_trim(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
+/* Free and total memory of the context's device in bytes (hipMemGetInfo), for hosts without a HIP runtime of their own; ctx == NULL: the device
+ * of the default contexts ($RMGR_SSIM_HIP_DEVICE).  Either pointer may be NULL.  ENODEV without a device. */
+rmgr_int32_t rmgr_ssim_hip_get_memory_info(const rmgr_ssim_hip_Context* ctx, rmgr_uint64_t* freeBytes, rmgr_uint64_t* totalBytes) RMGR_NOEXCEPT;
+
 /* ctx == NULL (set and get): the arithmetic mode of the process-wide default contexts the unchanged rmgr_ssim_compute_ssim() runs on
- * (a property of their pool, applied when a call leases one; the first is created on first use: ENODEV without a device).  This is what
+ * (a property of their pool, applied when a call leases one: calls in flight keep theirs; neither call waits for a lease or creates a context when
+ * one exists already -- only on an empty pool is the first context created, so that a machine without a device answers ENODEV).  This is what
  * rmgr::ssim::select_impl() calls (src/ssim.cpp:808-896). */
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* ctx, rmgr_int32_t mode) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* ctx, rmgr_int32_t* mode) RMGR_NOEXCEPT;
 
-/* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the kernel variant
- * (1: one column per lane, 2: two columns per lane, 3: two columns per lane with the bit-exact modes' (a,b) row sums formed a
- * phase early; the default picks by launch size).  Results do not depend on
- * either (tests/test_gpu_parity.py, tests/test_gpu_pipeline.py check). */
+/* Tuning knobs (0 = library default): rows of the image each wavefront strip covers, and the kernel variant --
+ *   1  one column per lane (64-column strips);            2  two columns per lane, row sums in the blur phase;
+ *   3  two columns per lane with the bit-exact modes' (a,b) row sums formed a phase early (EARLY);
+ *   6  the balanced schedule of the two-column kernel (launches without a map; modes 0, 3, 1) with the library's interleave of the images in
+ *      the chunk list; 7: without any interleave (round 5's list); 100 + T: T images interleaved (measurement aids, tools/phase_ab.sh);
+ * the default picks by launch size (rmgr_ssim_hip_get_plan reports what it picked; rmgr_ssim_hip_tune measures the candidates on the device).
+ * Results do not depend on either (tests/test_gpu_parity.py, tests/test_gpu_pipeline.py check). */
 rmgr_int32_t rmgr_ssim_hip_set_tuning(rmgr_ssim_hip_Context* ctx, rmgr_int32_t stripRows, rmgr_int32_t variant) RMGR_NOEXCEPT;
 
 /* How a launch of `count` width x height pairs is cut into wavefront strips under the context's mode and
@@ -105,17 +133,18 @@ typedef struct rmgr_ssim_hip_Plan
 {
     rmgr_uint32_t structSize;        /* in: sizeof(rmgr_ssim_hip_Plan) as the CALLER was compiled */
     rmgr_uint32_t stripWidth;        /* output columns per wavefront: 128 (two per lane) or 64 (one per lane: fp64 mode, tiny launches, tuning variant 1) */
-    rmgr_uint32_t stripRows;         /* output rows per wavefront */
-    rmgr_uint32_t stripsX, stripsY;  /* strips per image */
-    rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count = workgroups of the launch */
+    rmgr_uint32_t stripRows;         /* output rows per wavefront STRIP.  When balancedChunks > 0 this and the next four fields describe the strips a launch WITH a map */
+    rmgr_uint32_t stripsX, stripsY;  /* strips per image                  of these pairs runs; a launch without one runs balancedChunks wavefronts of balancedChunkRows rows, */
+    rmgr_uint32_t wavefronts;        /* stripsX * stripsY * count         in the EARLY form for modes 0 and 3 (128 x 1080p: 5760 strips with a map, 2041 chunks without) */
     /* -- RMGR_SSIM_HIP_PLAN_MIN_SIZE ends here -- */
     rmgr_uint32_t waveSlots;         /* wavefronts the device holds at a time with this kernel (SIMDs x waves per SIMD) */
-    rmgr_uint32_t earlyRowSums;      /* 1: the bit-exact two-column kernel runs in its EARLY form (launches of <= 3 x waveSlots wavefronts) */
+    rmgr_uint32_t earlyRowSums;      /* 1: the bit-exact two-column kernel's STRIPS run in the EARLY form (launches of <= 3 x waveSlots wavefronts) */
     rmgr_uint32_t cellRows;          /* rows of a reduction cell (64 columns x cellRows rows): 8, or 32 for images of >= 2048 rows */
     rmgr_uint32_t cellsX, cellsY;    /* the image's grid of reduction cells: cellsX * cellsY fp64 partials per image (rmgr_ssim_hip_enqueue_rows) */
     rmgr_uint32_t balancedChunks;    /* > 0: a launch of these pairs WITHOUT a map runs the balanced schedule of the two-column kernel (modes 0, 3, 1) -- this many */
-    rmgr_uint32_t balancedChunkRows; /*      wavefronts, each walking this many rows of the launch's flattened [image][strip column][row] list -- instead of */
+    rmgr_uint32_t balancedChunkRows; /*      wavefronts, each walking this many rows of the launch's flattened [images][strip column][row] list -- instead of */
                                      /*      the strips above (same results bit for bit; scheduling only); 0: the strips */
+    rmgr_uint32_t balancedInterleave;/* round 6: images interleaved column by column in that list (1: none): neighbouring strip columns of an image stay in step */
 } rmgr_ssim_hip_Plan;
 #define RMGR_SSIM_HIP_PLAN_MIN_SIZE 24u
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT;
@@ -294,6 +323,20 @@ rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* ctx, void* hostPtr,
  */
 rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* ctx, rmgr_int32_t enabled) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* ctx, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT;
+
+/*
+ * What the vector ALUs of the context's device sustain RIGHT NOW at a forced occupancy (profiling aid; no reference counterpart; not on
+ * the SSIM path).  A pure packed-fp32 instruction stream runs with its register footprint padded so that the hardware cannot place more
+ * than wavesPerSimd (1, 2, 3, 4 or 8) wavefronts on a SIMD, on a grid of exactly the device's capacity at that occupancy; streamKind 0:
+ * independent v_pk_fma_f32 (the issue peak at that occupancy), 1: two interleaved dependent chains of six (the blur's row sums).  Two
+ * untimed launches, then `launches` (1 ... 64) timed ones of about 2 ms each with HIP events on the context's stream; *teraLaneOps
+ * receives the MEDIAN launch's rate in 10^12 lane-operations per second (128 per packed instruction and wavefront).  The strip kernels are
+ * fp32-VALU bound and run at two (modes 0, 1, 3) or three (modes 2, 4) wavefronts per SIMD: bench.py divides their lane-operations per
+ * second by this figure, measured in the same process right before and right after the timed steps, instead of by a constant measured on
+ * another box.  Blocking.  EINVAL for any other occupancy or stream kind.
+ */
+rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* ctx, rmgr_int32_t wavesPerSimd, rmgr_int32_t streamKind, rmgr_int32_t launches,
+                                      double* teraLaneOps) RMGR_NOEXCEPT;
 
 /*
  * The synthetic test pattern the benchmark and the self-tests run on (no reference counterpart: the reference's

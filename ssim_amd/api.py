@@ -47,10 +47,10 @@ class Plan(ctypes.Structure):
     _fields_ = [("structSize", ctypes.c_uint32), ("stripWidth", ctypes.c_uint32), ("stripRows", ctypes.c_uint32), ("stripsX", ctypes.c_uint32),
                 ("stripsY", ctypes.c_uint32), ("wavefronts", ctypes.c_uint32), ("waveSlots", ctypes.c_uint32), ("earlyRowSums", ctypes.c_uint32),
                 ("cellRows", ctypes.c_uint32), ("cellsX", ctypes.c_uint32), ("cellsY", ctypes.c_uint32),
-                ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32)]
+                ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32), ("balancedInterleave", ctypes.c_uint32)]
 
 
-ABI_VERSION = 5      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
+ABI_VERSION = 6      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
 
 
 class ThreadPool(ctypes.Structure):
@@ -77,7 +77,8 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_synth_pair_device",
     "rmgr_ssim_hip_comm_get_unique_id", "rmgr_ssim_hip_comm_init", "rmgr_ssim_hip_comm_allreduce_sums", "rmgr_ssim_hip_comm_destroy",
     "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool", "rmgr_ssim_hip_get_kernel_source_id",
-    "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells",
+    "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells", "rmgr_ssim_hip_probe_valu",
+    "rmgr_ssim_hip_trim", "rmgr_ssim_hip_trim_default_pool", "rmgr_ssim_hip_get_default_pool_memory", "rmgr_ssim_hip_get_memory_info",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -139,6 +140,11 @@ def load_library(path=None):
         "rmgr_ssim_hip_comm_rank_count": [vp, ctypes.POINTER(i32)],
         "rmgr_ssim_hip_enqueue_rows": [vp, PP, u32, u32, vp],
         "rmgr_ssim_hip_reduce_cells": [vp, u32, u32, u32, vp, vp],
+        "rmgr_ssim_hip_probe_valu": [vp, i32, i32, i32, ctypes.POINTER(ctypes.c_double)],
+        "rmgr_ssim_hip_trim": [vp],
+        "rmgr_ssim_hip_trim_default_pool": [],
+        "rmgr_ssim_hip_get_default_pool_memory": [ctypes.POINTER(ctypes.c_uint64)] * 3,
+        "rmgr_ssim_hip_get_memory_info": [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
     }
     for name, args in sig.items():
         if path is None and os.environ.get("RMGR_SSIM_LIB") and not hasattr(lib, name):
@@ -249,6 +255,25 @@ def default_pool():
     return n.value, lim.value
 
 
+def default_pool_memory():
+    """(device bytes, pinned host bytes) the default contexts held when their last call ended, and the retain cap in bytes (per context)."""
+    d, p, c = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    _check("rmgr_ssim_hip_get_default_pool_memory", load_library().rmgr_ssim_hip_get_default_pool_memory(ctypes.byref(d), ctypes.byref(p), ctypes.byref(c)))
+    return d.value, p.value, c.value
+
+
+def trim_default_pool():
+    """Releases the staging of every default context that is not inside a call (rmgr_ssim_hip_trim_default_pool)."""
+    _check("rmgr_ssim_hip_trim_default_pool", load_library().rmgr_ssim_hip_trim_default_pool())
+
+
+def memory_info(ctx=None):
+    """(free, total) bytes of the context's device (ctx None: the default contexts' device)."""
+    f, t = ctypes.c_uint64(), ctypes.c_uint64()
+    _check("rmgr_ssim_hip_get_memory_info", load_library().rmgr_ssim_hip_get_memory_info(ctx.handle if ctx is not None else None, ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
+
+
 def compute_ssim_batch(pairs, ctx=None):
     """Global SSIM of many host image pairs of one size (rmgr_ssim_hip_compute_ssim_batch_host: pipelined staging).
     pairs: sequence of (a, b) uint8 arrays, H x W (any strides numpy can express along both axes)."""
@@ -357,6 +382,10 @@ class Context(object):
     def set_mode(self, mode):
         _check("rmgr_ssim_hip_set_mode", self.lib.rmgr_ssim_hip_set_mode(self.handle, mode))
 
+    def trim(self):
+        """Gives the context's grow-only staging back to the system (rmgr_ssim_hip_trim)."""
+        _check("rmgr_ssim_hip_trim", self.lib.rmgr_ssim_hip_trim(self.handle))
+
     def set_tuning(self, strip_rows=0, variant=0):
         _check("rmgr_ssim_hip_set_tuning", self.lib.rmgr_ssim_hip_set_tuning(self.handle, strip_rows, variant))
 
@@ -429,6 +458,12 @@ class Context(object):
         """Fill two device planes with the synthetic pair of SURVEY.md 8(d) (asynchronous on the context's stream)."""
         _check("rmgr_ssim_hip_synth_pair_device", self.lib.rmgr_ssim_hip_synth_pair_device(
             self.handle, a_ptr, a_stride, b_ptr, b_stride, width, height, seed))
+
+    def probe_valu(self, waves_per_simd, stream_kind=0, launches=5):
+        """T lane-ops/s a pure packed-fp32 stream sustains on this device right now at a forced occupancy (rmgr_ssim_hip_probe_valu)."""
+        t = ctypes.c_double()
+        _check("rmgr_ssim_hip_probe_valu", self.lib.rmgr_ssim_hip_probe_valu(self.handle, waves_per_simd, stream_kind, launches, ctypes.byref(t)))
+        return t.value
 
     def set_profiling(self, on):
         _check("rmgr_ssim_hip_set_profiling", self.lib.rmgr_ssim_hip_set_profiling(self.handle, 1 if on else 0))

@@ -30,6 +30,7 @@ using ssim_hip::PairDesc;
 struct rmgr_ssim_hip_Context_ {
     int         device;
     int         cu_count;
+    int         xcd_count;      // hipDeviceAttributeNumberOfXccs (8 on MI355X): the modulus of the kernels' XCD-aware workgroup order
     hipStream_t stream;
     bool        owns_stream;
     int         mode;
@@ -266,7 +267,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     for (uint32_t i = 0; i < count && all_fit; ++i)
         all_fit = ssim_hip::fits_strip2(descs[i], width, height);
     if (!all_fit) variant = 1;
-    ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, y_begin, y_rows);
+    ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, c->xcd_count, y_begin, y_rows);
     geo.wide = !all_fit;                             // the 64-bit form of the one-column kernel only where it is needed
     geo.map_unit = any_map && (width & 1u) == 0;     // the 8-byte map stores of the two-column kernel (ssim_kernels.hip, MAP == 2)
     for (uint32_t i = 0; i < count && geo.map_unit; ++i)
@@ -500,6 +501,129 @@ int compute_banded(rmgr_ssim_hip_Context* c, const rmgr_ssim_Params& p, const rm
 int comm_bounded_sync(rmgr_ssim_hip_Context* c);      // with the RCCL section below
 void comm_forget_collectives(rmgr_ssim_hip_Context* c);
 
+// ---- the caller's thread pool (rmgr_ssim_ThreadPool) ---------------------------------------------------------------------------
+// The reference cuts the image into 256 x 64 tiles and hands them to threadPool->dispatch as jobs: `fct` is to be called exactly jobCount
+// times with jobNum in [0, jobCount), on up to threadCount threads, args[t] used by one thread at a time; a non-zero return becomes ECHILD
+// -- when a global value was asked for (src/ssim.cpp:1048-1100, include/rmgr/ssim.h:448-466).  Rounds 1-5 validated the pool and never
+// called it.  Here the contract is kept with the unit of work this engine has on the HOST side: a ROW BAND of the pair -- its source rows
+// (with the 5-row halo) to the device, the strips of the band (a row window of the launch: cells at absolute positions, so any order and
+// any number of threads give the one-launch result bit for bit), and, with a map, the band's map rows back into the caller's buffer.  Jobs
+// are independent and may run in any order; the context itself is single-threaded, so a job holds the call's lock while it enqueues and
+// lets go of it while it waits for its map rows -- with several pool threads one band's copy-back overlaps the next band's copy-in and
+// kernel, as in the library's own pipeline (compute_banded()).  After dispatch returns: the fixed-order reduction of the cells, the mean.
+struct PoolCall {
+    rmgr_ssim_hip_Context* c;
+    const rmgr_ssim_Params* host;      // the caller's parameters (host pointers)
+    PairDesc d;                        // the staged pair (device pointers)
+    int64_t loA, loB;                  // byte offsets of the images' lowest addresses relative to topLeft
+    uint32_t jobs, band_rows;
+    bool whole;                        // the layout cannot be cut into row bands: one job stages the whole byte ranges
+    std::mutex m;
+    int rc;                            // first error of a job (errno)
+    uint32_t ran;                      // jobs that ran to their end
+    char done[rmgr_ssim_hip_Context_::kMaxBands];
+};
+
+void pool_job(void* arg, rmgr_uint32_t jobNum) RMGR_NOEXCEPT
+{
+    PoolCall& pc = **static_cast<PoolCall**>(arg);
+    rmgr_ssim_hip_Context* c = pc.c;
+    const rmgr_ssim_Params& p = *pc.host;
+    const uint32_t W = p.width, H = p.height;
+    int rc = 0;
+    DeviceGuard on_device(c->device);            // a pool thread has a current device of its own
+    std::unique_lock<std::mutex> lk(pc.m);
+    if (jobNum >= pc.jobs || pc.done[jobNum]) { if (!pc.rc) pc.rc = ECHILD; return; }      // a pool that invents or repeats jobs: "an error occurred in a worker"
+    if (on_device.rc) rc = on_device.rc;
+    const uint32_t y0 = jobNum * pc.band_rows, y1 = (uint32_t)std::min<uint64_t>((uint64_t)y0 + pc.band_rows, H);
+    if (!rc) {
+        const rmgr_ssim_ImgParams* img[2] = {&p.imgA, &p.imgB};
+        uint8_t* stage[2] = {const_cast<uint8_t*>(pc.d.a) + pc.loA, const_cast<uint8_t*>(pc.d.b) + pc.loB};      // = the staging buffers' first bytes
+        const int64_t lo_img[2] = {pc.loA, pc.loB};
+        for (int j = 0; j < 2 && !rc; ++j) {
+            int64_t lo, hi;
+            if (pc.whole) extent(*img[j], W, H, lo, hi);
+            else rows_extent(*img[j], W, y0 >= 5 ? y0 - 5 : 0, (uint32_t)std::min<uint64_t>((uint64_t)y1 + 5, H), lo, hi);      // the band's rows and its 5-row halo
+            const hipError_t e = hipMemcpyAsync(stage[j] + (lo - lo_img[j]), img[j]->topLeft + lo, (size_t)(hi - lo + 1), hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+        }
+    }
+    if (!rc) rc = enqueue(c, W, H, 1, &pc.d, p.ssimMap != NULL, c->h_sums, y0, y1 - y0, false);
+    if (!rc && p.ssimMap) {
+        const bool direct = p.ssimStep == 1 && p.ssimStride >= (ptrdiff_t)W;       // the DMA engine writes the caller's rows itself: no shared bounce buffers
+        if (direct) {
+            hipError_t e = c->band_done[jobNum] ? hipSuccess : hipEventCreateWithFlags(&c->band_done[jobNum], hipEventDisableTiming);
+            if (e == hipSuccess && !c->out_stream) e = hipStreamCreateWithFlags(&c->out_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventRecord(c->band_done[jobNum], c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->out_stream, c->band_done[jobNum], 0);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+            if (!rc) {
+                // the copy is queued behind this band's kernel on the third stream; the wait happens WITHOUT the call's lock
+                float* dst = p.ssimMap + (ptrdiff_t)y0 * p.ssimStride;
+                const float* src = c->stage_map + (size_t)y0 * W;
+                if (p.ssimStride == (ptrdiff_t)W) e = hipMemcpyAsync(dst, src, sizeof(float) * (size_t)(y1 - y0) * W, hipMemcpyDeviceToHost, c->out_stream);
+                else e = hipMemcpy2DAsync(dst, sizeof(float) * (size_t)p.ssimStride, src, sizeof(float) * W, sizeof(float) * W, y1 - y0, hipMemcpyDeviceToHost, c->out_stream);
+                hipEvent_t mine = NULL;
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&mine, hipEventDisableTiming);
+                if (e == hipSuccess) e = hipEventRecord(mine, c->out_stream);
+                lk.unlock();
+                if (e == hipSuccess) e = hipEventSynchronize(mine);
+                if (mine) (void)hipEventDestroy(mine);
+                if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); }
+                lk.lock();
+            }
+        } else {
+            rc = map_rows_to_host(c, p, y0, y1, c->stream);      // through the context's two bounce buffers: under the lock
+        }
+    }
+    if (rc) { if (!pc.rc) pc.rc = rc; return; }
+    pc.done[jobNum] = 1;
+    ++pc.ran;
+}
+
+// compute_ssim on host pointers through the caller's pool.  `dev` / `d`: the staged pair (buffers grown, nothing copied yet).
+int compute_via_pool(rmgr_ssim_hip_Context* c, float* ssim, const rmgr_ssim_Params& p, const PairDesc& d, int64_t loA, int64_t loB, const rmgr_ssim_ThreadPool& tp)
+{
+    const uint32_t W = p.width, H = p.height;
+    const uint32_t maxThreadCount = sizeof(void*) * 8;                               // the reference's cap (src/ssim.cpp:1025)
+    const uint32_t threads = std::min<uint32_t>(tp.threadCount, maxThreadCount);
+    PoolCall pc;
+    pc.c = c; pc.host = &p; pc.d = d; pc.loA = loA; pc.loB = loB; pc.rc = 0; pc.ran = 0;
+    memset(pc.done, 0, sizeof(pc.done));
+    pc.whole = !bandable(p);
+    int bands = 1;
+    if (W && H && !pc.whole) {
+        bands = (int)std::min<uint64_t>(((uint64_t)W * H + (1u << 21) - 1) >> 21, rmgr_ssim_hip_Context_::kMaxBands);       // ~2 Mpixel per band, as compute_banded()
+        if (!p.ssimMap) bands = std::min(bands, 4);
+        if (const char* e = getenv("RMGR_SSIM_HIP_BANDS")) bands = atoi(e);
+        bands = std::max(1, std::min<int>(bands, rmgr_ssim_hip_Context_::kMaxBands));
+    }
+    const uint32_t cell = ssim_hip::cell_rows_for(H);
+    pc.band_rows = std::max<uint32_t>(((H + bands - 1) / bands + cell - 1) & ~(cell - 1), cell);
+    pc.jobs = (W && H) ? (H + pc.band_rows - 1) / pc.band_rows : 0;                 // an empty image has no jobs (the reference dispatches its 0 tiles)
+    PoolCall* self = &pc;
+    void* args[sizeof(void*) * 8];
+    for (uint32_t t = 0; t < threads; ++t) args[t] = &self;
+    const int poolResult = tp.dispatch(tp.context, pool_job, args, threads, pc.jobs);
+    // whatever the pool did, nothing of this call may still be queued when the staging buffers are handed on
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->out_stream && hipStreamSynchronize(c->out_stream) != hipSuccess) (void)hipGetLastError();
+    if (e != hipSuccess) { (void)hipGetLastError(); return map_hip_error(e); }
+    if (pc.rc && pc.rc != ECHILD) return pc.rc;                                      // a HIP call failed inside a job
+    if (ssim == NULL) return 0;                                                      // src/ssim.cpp:1091: the pool's result is only looked at for the global value
+    if (poolResult != 0 || pc.rc || pc.ran != pc.jobs) return ECHILD;                // src/ssim.cpp:1094-1097 (and a pool that ran fewer jobs than it was given)
+    double sum = 0.0;
+    if (pc.jobs) {
+        const ssim_hip::Geometry geo = ssim_hip::plan(W, H, 1, c->mode, c->strip_rows, 0, c->cu_count, c->xcd_count);
+        e = ssim_hip::launch_reduce(geo, c->partials, c->partials + geo.partials_per_image(), c->h_sums, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); return map_hip_error(e); }
+        sum = c->h_sums[0];
+    }
+    *ssim = mean_of(sum, W, H);
+    return 0;
+}
+
 // ---- the process-wide default contexts of the drop-in entry points (ctx == NULL) -------------------------------------
 // The reference's compute_ssim() is re-entrant and has no global state (src/ssim.cpp:933-1106): six caller threads get six
 // computations running side by side.  Rounds 1-4 ran every ctx == NULL call on ONE default context under its lock: six
@@ -515,9 +639,21 @@ struct DefaultPool {
     std::vector<rmgr_ssim_hip_Context*> all, idle;
     int device, limit, mode, create_err;
     bool configured;
-    DefaultPool() : device(0), limit(4), mode(RMGR_SSIM_HIP_MODE_EXACT), create_err(0), configured(false) {}
+    // memory policy (round 6): staging a context may keep between calls, in bytes (device + pinned); what each context held when its last lease ended
+    uint64_t retain_cap;
+    struct Held { rmgr_ssim_hip_Context* c; uint64_t device_bytes, pinned_bytes; };
+    std::vector<Held> held;
+    DefaultPool() : device(0), limit(4), mode(RMGR_SSIM_HIP_MODE_EXACT), create_err(0), configured(false), retain_cap(uint64_t(256) << 20) {}
 };
-DefaultPool g_pool;       // never destroyed contexts: the process may still be inside a call at exit (as before)
+// A LEAKED singleton: neither the pool nor its contexts are ever destroyed.  The process may still be inside a ctx == NULL call when exit() runs
+// the static destructors or the library is unloaded (a daemon thread, a detached worker): its Lease must find the mutex, the condition variable
+// and the vectors alive when it ends (rounds 1-4 kept a raw pointer for the same reason).
+DefaultPool& pool()
+{
+    static DefaultPool* p = new DefaultPool;
+    return *p;
+}
+#define g_pool (pool())
 
 void pool_configure_locked()
 {
@@ -525,6 +661,10 @@ void pool_configure_locked()
     g_pool.configured = true;
     if (const char* s = getenv("RMGR_SSIM_HIP_DEVICE")) g_pool.device = atoi(s);
     if (const char* s = getenv("RMGR_SSIM_HIP_POOL")) { const int n = atoi(s); if (n >= 1 && n <= 64) g_pool.limit = n; }
+    if (const char* s = getenv("RMGR_SSIM_HIP_POOL_RETAIN_MB")) {       // per context; 0: keep nothing between calls (the reference's behaviour); negative: no cap
+        const long long mb = atoll(s);
+        g_pool.retain_cap = mb < 0 ? ~uint64_t(0) : (uint64_t)mb << 20;
+    }
     const char* m = getenv("RMGR_SSIM_HIP_MODE");
     if (m && atoi(m) >= RMGR_SSIM_HIP_MODE_EXACT && atoi(m) <= RMGR_SSIM_HIP_MODE_SEPARABLE) g_pool.mode = atoi(m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
@@ -573,9 +713,83 @@ int pool_acquire(rmgr_ssim_hip_Context** out)
     }
 }
 
+// What a context's grow-only staging holds right now (bytes of device memory / of pinned host memory).  Caller owns the context.
+void context_held(const rmgr_ssim_hip_Context* c, uint64_t& dev, uint64_t& pin)
+{
+    dev = (uint64_t)c->partials_cap * sizeof(double) + c->stage_a_cap + c->stage_b_cap + (uint64_t)c->stage_map_cap * sizeof(float)
+        + c->slot_dev_cap[0] + c->slot_dev_cap[1] + (uint64_t)c->batch_sums_cap * sizeof(double);
+    pin = (uint64_t)c->h_sums_cap * sizeof(double) + c->slot_pin_cap[0] + c->slot_pin_cap[1] + c->h_stage_cap
+        + ((uint64_t)c->h_map_cap[0] + c->h_map_cap[1]) * sizeof(float);
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
+        dev += (uint64_t)c->desc_slots[i].dev_cap * sizeof(PairDesc);
+        pin += (uint64_t)c->desc_slots[i].host_cap * sizeof(PairDesc);
+    }
+}
+
+// Gives a context's grow-only staging back to the system: device scratch, staged images and map, descriptor tables, pinned mirrors and bounce
+// buffers.  Streams, events, the communicator and the tuning stay; the next call grows what it needs again.  The context must be the caller's
+// (not in use by another thread); everything it has queued is waited for first.
+int context_trim(rmgr_ssim_hip_Context* c)
+{
+    DeviceGuard device_guard_(c->device);
+    if (device_guard_.rc) return device_guard_.rc;
+    int rc = 0;
+    if (!c->collectives.empty()) rc = comm_bounded_sync(c);
+    else { const hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); } }
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    if (c->out_stream) (void)hipStreamSynchronize(c->out_stream);
+    (void)hipGetLastError();
+    struct Drop {
+        static void dev(void* p) { if (p) (void)hipFree(p); }
+        static void pin(void* p) { if (p) (void)hipHostFree(p); }
+    };
+    Drop::dev(c->partials); c->partials = NULL; c->partials_cap = 0;
+    for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
+        rmgr_ssim_hip_Context_::DescSlot& s = c->desc_slots[i];
+        Drop::dev(s.dev); s.dev = NULL; s.dev_cap = 0;
+        Drop::pin(s.host); s.host = NULL; s.host_cap = 0;
+        s.live = 0; s.in_flight = false;
+    }
+    Drop::dev(c->stage_a); c->stage_a = NULL; c->stage_a_cap = 0;
+    Drop::dev(c->stage_b); c->stage_b = NULL; c->stage_b_cap = 0;
+    Drop::dev(c->stage_map); c->stage_map = NULL; c->stage_map_cap = 0;
+    Drop::pin(c->h_sums); c->h_sums = NULL; c->h_sums_cap = 0;
+    Drop::pin(c->h_stage); c->h_stage = NULL; c->h_stage_cap = 0;
+    for (int i = 0; i < 2; ++i) {
+        Drop::dev(c->slot_dev[i]); c->slot_dev[i] = NULL; c->slot_dev_cap[i] = 0;
+        Drop::pin(c->slot_pin[i]); c->slot_pin[i] = NULL; c->slot_pin_cap[i] = 0;
+        Drop::pin(c->h_map[i]); c->h_map[i] = NULL; c->h_map_cap[i] = 0;
+    }
+    Drop::dev(c->batch_sums); c->batch_sums = NULL; c->batch_sums_cap = 0;
+    (void)hipGetLastError();
+    return rc;
+}
+
+void pool_note_held_locked(rmgr_ssim_hip_Context* c, uint64_t dev, uint64_t pin)
+{
+    for (size_t i = 0; i < g_pool.held.size(); ++i)
+        if (g_pool.held[i].c == c) { g_pool.held[i].device_bytes = dev; g_pool.held[i].pinned_bytes = pin; return; }
+    try { const DefaultPool::Held h = {c, dev, pin}; g_pool.held.push_back(h); } catch (...) {}
+}
+
+// The lease ends: staging above the pool's retain cap ($RMGR_SSIM_HIP_POOL_RETAIN_MB, per context; default 256) goes back to the system
+// before the context becomes available again -- the reference keeps nothing past the call (src/ssim.cpp:1048-1088) -- and what the
+// context still holds is noted for rmgr_ssim_hip_get_default_pool_memory.
 void pool_release(rmgr_ssim_hip_Context* c)
 {
-    { std::lock_guard<std::mutex> lk(g_pool.m); g_pool.idle.push_back(c); }
+    uint64_t cap;
+    { std::lock_guard<std::mutex> lk(g_pool.m); cap = g_pool.retain_cap; }
+    uint64_t dev = 0, pin = 0;
+    context_held(c, dev, pin);
+    if (dev + pin > cap) {
+        (void)context_trim(c);
+        context_held(c, dev, pin);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        pool_note_held_locked(c, dev, pin);
+        g_pool.idle.push_back(c);
+    }
     g_pool.freed.notify_one();
 }
 
@@ -627,6 +841,12 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     if (!c) return ENOMEM;
     c->device = device;
     c->cu_count = prop.multiProcessorCount;
+    c->xcd_count = 8;
+    {
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xccs >= 1) c->xcd_count = xccs;
+        else (void)hipGetLastError();
+    }
     c->stream = static_cast<hipStream_t>(stream);
     c->owns_stream = false;
     c->mode = RMGR_SSIM_HIP_MODE_EXACT;
@@ -658,8 +878,8 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
         if (e != hipSuccess) { delete c; return map_hip_error(e); }
         c->owns_stream = true;
     }
-    snprintf(c->describe, sizeof(c->describe), "%s %s, %d CUs, %.0f MHz, %.1f GiB; rmgr-ssim hip backend (code object gfx950)",
-             prop.name, prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0);
+    snprintf(c->describe, sizeof(c->describe), "%s %s, %d CUs in %d XCDs, %.0f MHz, %.1f GiB; rmgr-ssim hip backend (code object gfx950)",
+             prop.name, prop.gcnArchName, prop.multiProcessorCount, c->xcd_count, prop.clockRate / 1000.0, prop.totalGlobalMem / 1073741824.0);
     *out = c;
     return 0;
 }
@@ -705,14 +925,30 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     return 0;
 }
 
+// ctx == NULL set_mode / get_mode touch an int of the pool: when a default context exists they need no lease (they used to wait behind
+// $RMGR_SSIM_HIP_POOL calls in flight, or create another context, to learn whether a device exists).  Only an EMPTY pool leases -- i.e. creates
+// its first context -- to keep the contract that the call fails with ENODEV on a machine without a device (select_impl() returns 0 there).
+namespace {
+int default_pool_has_device()
+{
+    {
+        std::lock_guard<std::mutex> guard(g_pool.m);
+        pool_configure_locked();
+        for (size_t i = 0; i < g_pool.all.size(); ++i)
+            if (g_pool.all[i] != NULL) return 0;
+    }
+    Lease probe;
+    return probe.take(NULL);
+}
+} // namespace
+
 rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode) RMGR_NOEXCEPT
 {
     if (mode < RMGR_SSIM_HIP_MODE_EXACT || mode > RMGR_SSIM_HIP_MODE_SEPARABLE) return EINVAL;
     if (!c) {
         // the process-wide default contexts of the drop-in entry points (what rmgr::ssim::select_impl switches): a property of the
-        // pool, applied to a context when a call leases it.  As before the call needs a device (ENODEV without one).
-        Lease probe;
-        const int rc = probe.take(NULL);
+        // pool, applied to a context when a call leases it (calls already in flight keep the mode they were leased with).
+        const int rc = default_pool_has_device();
         if (rc) return rc;
         std::lock_guard<std::mutex> guard(g_pool.m);
 #if defined(RMGR_SSIM_USE_DOUBLE) && RMGR_SSIM_USE_DOUBLE
@@ -728,9 +964,8 @@ rmgr_int32_t rmgr_ssim_hip_set_mode(rmgr_ssim_hip_Context* c, rmgr_int32_t mode)
 rmgr_int32_t rmgr_ssim_hip_get_mode(const rmgr_ssim_hip_Context* c, rmgr_int32_t* mode) RMGR_NOEXCEPT
 {
     if (!mode) return EINVAL;
-    if (!c) {                 // the process-wide default contexts, as for set_mode (created on first use; ENODEV without a device)
-        Lease probe;
-        const int rc = probe.take(NULL);
+    if (!c) {                 // the process-wide default contexts, as for set_mode (ENODEV without a device)
+        const int rc = default_pool_has_device();
         if (rc) return rc;
         std::lock_guard<std::mutex> guard(g_pool.m);
         *mode = g_pool.mode;
@@ -765,6 +1000,67 @@ rmgr_int32_t rmgr_ssim_hip_get_default_pool(rmgr_int32_t* contexts, rmgr_int32_t
     return 0;
 }
 
+rmgr_int32_t rmgr_ssim_hip_get_default_pool_memory(rmgr_uint64_t* deviceBytes, rmgr_uint64_t* pinnedBytes, rmgr_uint64_t* retainCapBytes) RMGR_NOEXCEPT
+{
+    std::lock_guard<std::mutex> lk(g_pool.m);
+    pool_configure_locked();
+    uint64_t dev = 0, pin = 0;
+    for (size_t i = 0; i < g_pool.held.size(); ++i) { dev += g_pool.held[i].device_bytes; pin += g_pool.held[i].pinned_bytes; }
+    if (deviceBytes) *deviceBytes = dev;
+    if (pinnedBytes) *pinnedBytes = pin;
+    if (retainCapBytes) *retainCapBytes = g_pool.retain_cap;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_trim_default_pool(void) RMGR_NOEXCEPT
+{
+    // the idle contexts leave the pool while they are trimmed (no call can lease one half-freed); contexts in use are left alone
+    std::vector<rmgr_ssim_hip_Context*> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        mine.swap(g_pool.idle);
+    }
+    int rc = 0;
+    for (size_t i = 0; i < mine.size(); ++i) {
+        const int r = context_trim(mine[i]);
+        if (r && !rc) rc = r;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool.m);
+        for (size_t i = 0; i < mine.size(); ++i) {
+            uint64_t dev = 0, pin = 0;
+            context_held(mine[i], dev, pin);
+            pool_note_held_locked(mine[i], dev, pin);
+            g_pool.idle.push_back(mine[i]);
+        }
+    }
+    g_pool.freed.notify_all();
+    return rc;
+}
+
+rmgr_int32_t rmgr_ssim_hip_trim(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    if (!c) return rmgr_ssim_hip_trim_default_pool();
+    return context_trim(c);
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_memory_info(const rmgr_ssim_hip_Context* c, rmgr_uint64_t* freeBytes, rmgr_uint64_t* totalBytes) RMGR_NOEXCEPT
+{
+    int device;
+    if (c) device = c->device;
+    else { std::lock_guard<std::mutex> lk(g_pool.m); pool_configure_locked(); device = g_pool.device; }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return ENODEV; }
+    if (device < 0 || device >= n) return EINVAL;
+    DeviceGuard device_guard_(device);
+    if (device_guard_.rc) return device_guard_.rc;
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (freeBytes) *freeBytes = f;
+    if (totalBytes) *totalBytes = t;
+    return 0;
+}
+
 rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT
 {
     return RMGR_SSIM_HIP_ABI_VERSION;
@@ -773,10 +1069,10 @@ rmgr_int32_t rmgr_ssim_hip_get_abi_version(void) RMGR_NOEXCEPT
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT
 {
     if (!plan || plan->structSize < RMGR_SSIM_HIP_PLAN_MIN_SIZE) return EINVAL;
-    const int mode = c ? c->mode : RMGR_SSIM_HIP_MODE_EXACT, cus = c ? c->cu_count : 256, rows = c ? c->strip_rows : 0;
+    const int mode = c ? c->mode : RMGR_SSIM_HIP_MODE_EXACT, cus = c ? c->cu_count : 256, xcds = c ? c->xcd_count : 8, rows = c ? c->strip_rows : 0;
     int variant = c ? c->variant : 0;
     if (variant == 0 && rows == 0) variant = ssim_hip::default_variant(width, height, count, mode, cus);    // as enqueue() does
-    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, mode, rows, variant, cus);
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, mode, rows, variant, cus, xcds);
     rmgr_ssim_hip_Plan full;
     memset(&full, 0, sizeof(full));
     full.structSize = plan->structSize;
@@ -792,6 +1088,7 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* c, rmgr_uint32_
     full.cellsY = geo.cells_y;
     full.balancedChunks = geo.n_chunks;
     full.balancedChunkRows = geo.chunk_cells * geo.cell_rows;
+    full.balancedInterleave = geo.n_chunks ? geo.bal_stride : 0u;
     memcpy(plan, &full, std::min<size_t>(plan->structSize, sizeof(full)));      // never beyond what the caller allocated
     return 0;
 }
@@ -845,7 +1142,7 @@ rmgr_int32_t rmgr_ssim_hip_reduce_cells(rmgr_ssim_hip_Context* c, rmgr_uint32_t 
     if (!c || (count && (!cellsDevice || !sumsDevice))) return EINVAL;
     if (count == 0) return 0;
     USE_DEVICE(c);
-    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count);
+    const ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, c->variant, c->cu_count, c->xcd_count);
     int rc = grow_device(c->partials, c->partials_cap, ssim_hip::reduce_scratch_size(geo) + 1);     // the chunk sums of very large images
     if (rc) return rc;
     HIP_TRY(ssim_hip::launch_reduce(geo, cellsDevice, c->partials, sumsDevice, c->stream));
@@ -998,6 +1295,7 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     (void)rel;
 
     rmgr_ssim_Params dev = *params;
+    const bool pooled = threadPool != NULL && threadPool->dispatch != NULL;
     bool staged = true;                  // false: the large-image copies are still to be issued
     int64_t loA = 0, hiA = 0, loB = 0, hiB = 0;
     if (W && H) {
@@ -1011,9 +1309,11 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
             const size_t offB = (nA + 63) & ~(size_t)63;
             if ((rc = grow_pinned(c->h_stage, c->h_stage_cap, offB + nB))) return rc;
             if ((rc = grow_device(c->stage_a, c->stage_a_cap, offB + nB))) return rc;
-            memcpy(c->h_stage, params->imgA.topLeft + loA, nA);
-            memcpy(c->h_stage + offB, params->imgB.topLeft + loB, nB);
-            HIP_TRY(hipMemcpyAsync(c->stage_a, c->h_stage, offB + nB, hipMemcpyHostToDevice, c->stream));
+            if (!pooled) {                    // with the caller's thread pool the images are sent by its jobs (compute_via_pool())
+                memcpy(c->h_stage, params->imgA.topLeft + loA, nA);
+                memcpy(c->h_stage + offB, params->imgB.topLeft + loB, nB);
+                HIP_TRY(hipMemcpyAsync(c->stage_a, c->h_stage, offB + nB, hipMemcpyHostToDevice, c->stream));
+            }
             dev.imgA.topLeft = c->stage_a - loA;
             dev.imgB.topLeft = c->stage_a + offB - loB;
         } else {
@@ -1044,6 +1344,8 @@ rmgr_int32_t rmgr_ssim_hip_compute_ssim_host(rmgr_ssim_hip_Context* c, float* ss
     // Without a map a few bands hide the kernel behind the copy, which pays only for very large images (compute_banded()).
     // An explicit $RMGR_SSIM_HIP_BANDS always takes the banded path (so that a band sweep measures what it says it does).
     const bool bands_forced = getenv("RMGR_SSIM_HIP_BANDS") != NULL;
+    if (pooled)           // the caller brought a thread pool: its dispatch function runs the row-band jobs
+        return compute_via_pool(c, ssim, *params, d, loA, loB, *threadPool);
     if (!staged && bandable(*params) && (params->ssimMap || bands_forced || (uint64_t)W * H >= (uint64_t(1) << 26))) {
         if ((rc = compute_banded(c, *params, dev, d, loA, loB))) return rc;
     } else {
@@ -1753,6 +2055,38 @@ rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* c, rmgr_uint64_t* 
     if (kernelMs) *kernelMs = c->prof_ms;
     c->prof_launches = 0;
     c->prof_ms = 0.0;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* c, rmgr_int32_t wavesPerSimd, rmgr_int32_t streamKind, rmgr_int32_t launches, double* teraLaneOps) RMGR_NOEXCEPT
+{
+    if (!c || !teraLaneOps || launches < 1 || launches > 64 || (streamKind != 0 && streamKind != 1)) return EINVAL;
+    if (wavesPerSimd != 1 && wavesPerSimd != 2 && wavesPerSimd != 3 && wavesPerSimd != 4 && wavesPerSimd != 8) return EINVAL;
+    USE_DEVICE(c);
+    // ~2 ms per launch at any occupancy (the strip kernel's own duration on the headline batch): a SIMD retires one packed instruction per
+    // 4.2 ... 4.9 clocks, so W waves x 24 instructions x iters / 2.4 GHz ~ 2 ms  ->  iters ~ 40000 / W
+    const int iters = 40000 / wavesPerSimd;
+    int rc = grow_device(c->partials, c->partials_cap, 64);        // the kernel's (never written) output pointer
+    if (rc) return rc;
+    hipEvent_t eb = NULL, ee = NULL;
+    HIP_TRY(hipEventCreate(&eb));
+    hipError_t err = hipEventCreate(&ee);
+    if (err != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(eb); return map_hip_error(err); }
+    float ms[64];
+    for (int k = -2; k < launches && err == hipSuccess; ++k) {
+        if (k >= 0) err = hipEventRecord(eb, c->stream);
+        if (err == hipSuccess) err = ssim_hip::launch_probe_valu(wavesPerSimd, streamKind, c->cu_count, iters, reinterpret_cast<float*>(c->partials), c->stream);
+        if (k >= 0 && err == hipSuccess) err = hipEventRecord(ee, c->stream);
+        if (k >= 0 && err == hipSuccess) err = hipEventSynchronize(ee);
+        if (k >= 0 && err == hipSuccess) err = hipEventElapsedTime(&ms[k], eb, ee);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(eb); (void)hipEventDestroy(ee);
+    if (err != hipSuccess) { (void)hipGetLastError(); return map_hip_error(err); }
+    std::sort(ms, ms + launches);
+    const float med = ms[launches / 2];
+    if (!(med > 0.f)) return ECHILD;
+    *teraLaneOps = (double)ssim_hip::probe_valu_lane_ops(wavesPerSimd, c->cu_count, iters) / ((double)med * 1e-3) / 1e12;
     return 0;
 }
 

@@ -35,6 +35,8 @@ struct Geometry {
     uint32_t wave_slots;          // strips the chip holds at a time with this kernel (SIMDs x waves per SIMD): plan()'s packing unit
     uint32_t chunk_cells;         // > 0: the balanced schedule of the two-column kernel -- every wavefront covers this many cell rows of the launch's
     uint32_t n_chunks;            //      flattened [image][strip column][cell row] list (n_chunks wavefronts); 0: one strip per wavefront
+    uint32_t bal_stride;          // balanced schedule: images interleaved column by column in the list (1: none); ssim_kernels.hip work_setup()
+    uint32_t xcds;                // XCDs of the device (hipDeviceAttributeNumberOfXccs): the workgroup renumbering's modulus
     uint32_t partials_per_image() const { return cells_x * cells_y; }
 };
 
@@ -88,6 +90,10 @@ inline int default_variant(uint32_t width, uint32_t height, uint32_t count, int 
 // cells -1.5...-3 %; profiles/r02_cells_ab.txt).
 inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8u; }
 
+// Tuning variants that force the balanced schedule of the two-column kernel: 6 with plan()'s interleave of the images in the chunk list, 7 without
+// any (round 5's list), 100 + T with T images interleaved (measurement aids; ssim_kernels.hip work_setup()).
+inline bool is_balanced_variant(int variant) { return variant == 6 || variant == 7 || variant >= 100; }
+
 // Which launches run the EARLY form of the bit-exact two-column kernel by default.  Measured with both forms interleaved in
 // one process over batch sizes (profiles/r03_early_sweep.txt; rounds = strips / wave slots of the chip): up to ~2 rounds EARLY
 // wins 2.4...5 % (one 4096^2 pair 169.5 -> 173.5 Gpix/s, 8 x 4096^2 201 -> 206, 2 x 8192^2 + map 190 -> 200, 32 x 1080p
@@ -98,7 +104,7 @@ inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8
 inline bool uses_early_row_sums(const Geometry& geo, int mode, int variant)
 {
     if ((mode != MODE_EXACT && mode != MODE_UNFUSED) || variant == 1 || geo.strip_w != 128) return false;
-    if (variant == 3 || variant == 6) return true;      // 6: the balanced schedule, which exists with EARLY row sums only
+    if (variant == 3 || is_balanced_variant(variant)) return true;      // the balanced schedule exists with EARLY row sums only
     if (variant != 0) return false;
     const uint64_t strips = (uint64_t)geo.strips_x * geo.strips_y * geo.count;
     return geo.wave_slots != 0 && strips <= 3ull * geo.wave_slots;
@@ -107,7 +113,8 @@ inline bool uses_early_row_sums(const Geometry& geo, int mode, int variant)
 // y_begin / y_rows: the output rows the launch produces (default: the whole image).  A host that pipelines an image
 // in row bands launches consecutive windows -- each starting on a cell boundary -- into the same partials and
 // asks for the reduction with the last one; the sums are bit-identical to the single launch's.
-Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count,
+// cu_count / xcd_count: the device's (hipDeviceProp_t::multiProcessorCount, hipDeviceAttributeNumberOfXccs); <= 0: MI355X's 256 / 8.
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count, int xcd_count,
               uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu);
 
 // Doubles of device scratch launch() needs for `geo` (cell partials + the chunk sums of the two-stage reduction).
@@ -142,6 +149,12 @@ hipError_t launch_luminance(uint8_t* dst, int64_t dst_stride, const uint8_t* src
 // oracle_synth_pair are its host twins), written straight into device memory: A and B planes, rows stride bytes apart.
 hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b_stride, uint32_t width, uint32_t height,
                              uint64_t seed, hipStream_t stream);
+
+// Profiling aid (ssim_probe.hip): a pure packed-fp32 stream at a FORCED occupancy of waves_per_simd (1, 2, 3, 4 or 8) waves per SIMD on
+// a grid of exactly cu_count x 4 x waves_per_simd single-wave workgroups; stream_kind 0: independent v_pk_fma_f32, 1: two interleaved
+// dependent chains of six (the shape of the blur's row sums).  probe_valu_lane_ops(): the lane-operations one such launch retires.
+hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream);
+uint64_t probe_valu_lane_ops(int waves_per_simd, int cu_count, int iters);
 
 } // namespace ssim_hip
 

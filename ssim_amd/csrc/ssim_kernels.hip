@@ -404,6 +404,8 @@ struct KArgs {
     uint32_t        chunk_cells;  // 0: one strip per workgroup (grid strips_x x strips_y x count); > 0: the BALANCED schedule -- workgroup w covers cell rows
                                   // [w * chunk_cells, ...) of the launch's flattened [image][strip column][cell row] list, continuing into the next column / image
     uint32_t        n_chunks;     // workgroups of the balanced schedule (1-D grid)
+    uint32_t        bal_stride;   // balanced schedule: T >= 1 images are interleaved column by column in the flattened list (list position -> image, column: list_column())
+    uint32_t        xcds;         // XCDs the dispatcher deals consecutive workgroups to (hipDeviceAttributeNumberOfXccs; 8 on MI355X)
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
@@ -429,6 +431,17 @@ struct Strip {
     uint32_t sx, sy, img;
 };
 
+// Workgroup g of `total` -> its place in the work list when each of the `xcds` XCDs (which the dispatcher deals consecutive
+// workgroup ids to, round robin) is to walk ONE contiguous share of the list: XCD k owns total / xcds entries, the first
+// total % xcds XCDs one more.  A bijection for any total and any XCD count; wave-uniform scalar arithmetic.
+__device__ __forceinline__ uint32_t xcd_order(uint32_t g, uint32_t total, uint32_t xcds)
+{
+    uint32_t xcd, slot, q, rem;
+    if (xcds == 8) { xcd = g & 7u; slot = g >> 3; q = total >> 3; rem = total & 7u; }      // MI355X: no division
+    else           { slot = g / xcds; xcd = g - slot * xcds; q = total / xcds; rem = total - q * xcds; }
+    return xcd * q + (xcd < rem ? xcd : rem) + slot;
+}
+
 __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
 {
     Strip st;
@@ -441,7 +454,7 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     // channels of an interleaved pixel format); their strips at one position then run back to back on one XCD
     // and share its L2 lines (position-major, sibling-minor walk) instead of each channel re-fetching them.
     const uint32_t per_img = args.strips_x * args.strips_y;
-    if ((per_img & 7u) == 0 && args.group <= 1) {
+    if (args.xcds == 8 && (per_img & 7u) == 0 && args.group <= 1) {
         // the common case needs no division by per_img: every image's strip list splits into eighths
         const uint32_t lin = blockIdx.y * args.strips_x + blockIdx.x;
         const uint32_t swz = (lin & 7u) * (per_img >> 3) + (lin >> 3);
@@ -451,8 +464,7 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
     } else {
         const uint32_t total = per_img * args.count;
         const uint32_t g = (blockIdx.z * args.strips_y + blockIdx.y) * args.strips_x + blockIdx.x;
-        const uint32_t xcd = g & 7u, slot = g >> 3, q = total >> 3, rem = total & 7u;
-        const uint32_t id = xcd * q + (xcd < rem ? xcd : rem) + slot;  // XCD k owns q (+1 for the first `rem`) strips
+        const uint32_t id = xcd_order(g, total, args.xcds);
         uint32_t lin;
         if (args.group > 1) {
             const uint32_t span = per_img * args.group;
@@ -489,31 +501,56 @@ __device__ __forceinline__ Strip strip_setup(const KArgs& args, int strip_w)
 // (a segment = the part inside one strip column: what a strip is), continuing into the next strip column or image.  Cells, maps
 // and sums are the strips' bit for bit.  It pays where the strips leave a partial round and LOSES elsewhere (a static equal
 // partition needs every SIMD to run at the same speed for the whole launch): which launches take it is plan()'s measured rule.
-// The work of one wavefront: `n` cell rows starting at cell row `cy` of strip column `sx` of image `img`.
-struct Work { uint32_t img, sx, cy, n; };
+// Round 6: the PHASE of the chunks.  A wavefront reads three 128-byte lines per source row and image -- its own and a few bytes of each
+// horizontal neighbour's -- and the XCD's 4 MiB L2 holds ~20 rows of its 256 wavefronts: two of the three lines hit only if the neighbouring
+// strip columns of an image are walked within ~20 rows of each other.  The strips are (all start together at the same rows).  Equal chunks of
+// c cell rows cut out of columns of C are not: chunk k starts at cell row k c mod C of its column, so neighbouring columns are C mod c cell
+// rows out of step (128 x 1080p, c = 127, C = 135: 64 rows) and round 5's launch fetched 2.9...3.0x its algorithmic bytes where the strips fetch
+// 1.02...1.12x -- and ran up to 2.3 % slower for it (profiles/r06_phase_ab.txt).  Remedy: T images are INTERLEAVED column by column in the
+// list (list positions k T + i hold column k of the block's image i), with T chosen by plan() so that T (C mod c) is within a cell row or so of
+// a multiple of c: neighbouring columns of one image, T list positions apart, are then that little out of step instead of C mod c.
+// 128 x 1080p (T = 16): 2.90x -> 1.04x, +2.3 %; 96 x 1080p (T = 19) +2.7 %; 64 x 1080p (T = 9) 2.94x -> 1.24x; 32 x 1080p 3.01x -> 1.53x (what is
+// left there: the columns at the ends of an XCD's share, whose neighbours another XCD walks).  Also measured: a chunk's two segments walked
+// last to first (every wavefront starts a column at its row 0): 128 x 1080p 1.12x, +1.3 % -- the interleave is better everywhere and is what ships.
+// Same segments, same cells, same sums: only which wavefront takes which segment.
+// List position `col` of the flattened [block of T images][strip column][image of the block] list -> image and strip column.
+__device__ __forceinline__ void list_column(const KArgs& args, uint32_t col, uint32_t& img, uint32_t& sx)
+{
+    const uint32_t T = args.bal_stride;
+    if (T <= 1) {
+        img = col / args.strips_x;
+        sx = col - img * args.strips_x;
+        return;
+    }
+    const uint32_t span = T * args.strips_x, blk = col / span, within = col - blk * span;
+    const uint32_t left = args.count - blk * T, here = left < T ? left : T;     // the last block may hold fewer images
+    sx = within / here;
+    img = blk * T + (within - sx * here);
+}
+
+// The work of one wavefront: cell rows [first, end) of the flattened list; `first` moves up as segments are taken.
+struct Work { uint32_t first, end; };
 
 __device__ __forceinline__ Work work_setup(const KArgs& args)
 {
     Work w;
-    // each XCD walks a contiguous eighth of the chunk list (strip_setup)
-    const uint32_t b = blockIdx.x, total = args.n_chunks;
-    const uint32_t xcd = b & 7u, slot = b >> 3, q = total >> 3, rem = total & 7u;
-    const uint32_t id = xcd * q + (xcd < rem ? xcd : rem) + slot;
+    // each XCD walks a contiguous share of the chunk list (strip_setup)
+    const uint32_t id = xcd_order(blockIdx.x, args.n_chunks, args.xcds);
     const uint32_t all = args.count * args.strips_x * args.col_cells;      // < 2^31 (plan())
-    const uint32_t first = id * args.chunk_cells;
-    w.n = all - first < args.chunk_cells ? all - first : args.chunk_cells;
-    const uint32_t col = first / args.col_cells;
-    w.cy = first - col * args.col_cells;
-    w.img = col / args.strips_x;
-    w.sx = col - w.img * args.strips_x;
+    w.first = id * args.chunk_cells;
+    w.end = all - w.first < args.chunk_cells ? all : w.first + args.chunk_cells;
     return w;
 }
 
-// The next segment of `w` as a Strip; advances `w`.
+// The next segment of `w` as a Strip; shrinks `w`.
 __device__ __forceinline__ Strip segment_setup(const KArgs& args, Work& w, int strip_w)
 {
     Strip st;
-    st.img = w.img; st.sx = w.sx; st.sy = 0;
+    const uint32_t col = w.first / args.col_cells, cy = w.first - col * args.col_cells;
+    const uint32_t seg = args.col_cells - cy < w.end - w.first ? args.col_cells - cy : w.end - w.first;
+    w.first += seg;
+    list_column(args, col, st.img, st.sx);
+    st.sy = 0;
     st.pd = args.single;
     if (args.descs) {
         const gptr_desc gd = (gptr_desc)args.descs + st.img;
@@ -521,18 +558,11 @@ __device__ __forceinline__ Strip segment_setup(const KArgs& args, Work& w, int s
         st.pd.b = (const uint8_t*)uniform64((int64_t)gd->b); st.pd.b_step = uniform64(gd->b_step); st.pd.b_stride = uniform64(gd->b_stride);
         st.pd.map = (float*)uniform64((int64_t)gd->map); st.pd.map_step = uniform64(gd->map_step); st.pd.map_stride = uniform64(gd->map_stride);
     }
-    const uint32_t seg = args.col_cells - w.cy < w.n ? args.col_cells - w.cy : w.n;
     st.W = args.width; st.H = args.height;
     st.x0 = (int64_t)st.sx * strip_w;
-    st.y0 = (int64_t)args.y_begin + ((int64_t)w.cy << args.cell_shift);
+    st.y0 = (int64_t)args.y_begin + ((int64_t)cy << args.cell_shift);
     const int64_t ye = st.y0 + ((int64_t)seg << args.cell_shift);
     st.y_end = ye < (int64_t)args.y_end ? ye : (int64_t)args.y_end;
-    w.n -= seg;
-    w.cy += seg;
-    if (w.cy == args.col_cells) {
-        w.cy = 0;
-        if (++w.sx == args.strips_x) { w.sx = 0; ++w.img; }
-    }
     return st;
 }
 
@@ -678,7 +708,7 @@ void ssim_strip2_kernel(const KArgs args)
     // the separable taps as six scalars (an array inside the kernel argument block, passed on by reference, can end up
     // in scratch memory when scalar and packed streams both use it)
     const float gf[6] = {args.gf[0], args.gf[1], args.gf[2], args.gf[3], args.gf[4], args.gf[5]};
-    Work wk = {0, 0, 0, 0};
+    Work wk = {0, 0};
     if constexpr (BAL) wk = work_setup(args);
 #pragma unroll 1
     do {                                // BAL: one pass per segment of the wavefront's chunk; otherwise once: the wavefront's strip
@@ -1021,7 +1051,7 @@ void ssim_strip2_kernel(const KArgs args)
         cell_batch_flush2(args, st, cells, cell_y, parked);
     }
     if constexpr (BAL) wave_sync();     // the next segment re-uses the LDS slots and the cell batch
-    } while (BAL && wk.n != 0);
+    } while (BAL && wk.end > wk.first);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1487,8 +1517,8 @@ static int waves_per_simd(int mode, int variant)
 {
     (void)variant;
     if (mode == MODE_DOUBLE) return 3;                       // 160 VGPRs
-    if (mode == MODE_SEPARABLE) return 3;                    // two columns: 164-166 VGPRs; one column: 105 (4 waves, planned as 3)
-    return 2;                                                // bit-exact modes and MODE_FAST: 233 VGPRs (one column without map: 146, planned as 2)
+    if (mode == MODE_SEPARABLE) return 3;                    // two columns: 146 VGPRs since round 5 (168 before); one column: 105 (4 waves, planned as 3)
+    return 2;                                                // bit-exact modes 224-228 VGPRs, MODE_FAST 208 (round 5; 232 / 227 before); one column without map: 146, planned as 2
 }
 
 static int columns_per_lane(int mode, int variant)
@@ -1497,13 +1527,14 @@ static int columns_per_lane(int mode, int variant)
     return variant == 1 ? 1 : 2;   // variant 1: one column per lane (lower VGPR use, more waves)
 }
 
-Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count,
+Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int strip_rows, int variant, int cu_count, int xcd_count,
               uint32_t y_begin, uint32_t y_rows)
 {
     Geometry g;
     g.width = width; g.height = height; g.count = count;
     g.map_unit = false;
     g.wide = true;          // safe default; the caller clears it when every pair passes fits_strip2()
+    g.xcds = xcd_count >= 1 ? (uint32_t)xcd_count : 8u;     // the modulus of the kernels' XCD-aware workgroup order (scheduling only)
     g.wave_slots = (uint32_t)((cu_count > 0 ? cu_count : 256) * 4 * waves_per_simd(mode, variant));
     g.strip_w = 64 * columns_per_lane(mode, variant);
     g.strips_x = (width + g.strip_w - 1) / g.strip_w;
@@ -1575,13 +1606,13 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
     // alone everything the chunks lose on (8 x 1080p -7 %, 12 / 24 x 4096^2 -3 / -5 %, 192...384 x 1080p -2...-3.5 %) or only tie.
     // MODE_FAST, same rule, same shapes: +5.1 / +5.4 / +6.6 / +3.8 / +5.5 / +3.4 % and +5.1 %.  MODE_SEPARABLE (three waves per SIMD) LOSES with chunks
     // nearly everywhere (-1...-17 %; at best +2 %): it keeps its strips and has no balanced instantiation.
-    g.chunk_cells = 0; g.n_chunks = 0;
-    if ((mode == MODE_EXACT || mode == MODE_UNFUSED || mode == MODE_FAST) && g.strip_w == 128 && rows_total > 0 && (variant == 6 || (variant == 0 && default_rows))) {
+    g.chunk_cells = 0; g.n_chunks = 0; g.bal_stride = 1;
+    if ((mode == MODE_EXACT || mode == MODE_UNFUSED || mode == MODE_FAST) && g.strip_w == 128 && rows_total > 0 && (is_balanced_variant(variant) || (variant == 0 && default_rows))) {
         const uint64_t col_cells = (rows_total + cr - 1) / cr, all = (uint64_t)count * g.strips_x * col_cells;
         const uint64_t want = g.wave_slots;
         if (all > want && all < (1ull << 31)) {
             const uint64_t chunk = (all + want - 1) / want, n_chunks = (all + chunk - 1) / chunk;
-            bool take = variant == 6;
+            bool take = is_balanced_variant(variant);
             if (!take && strips_cost != 0 && chunk * cr <= 1100 && chunk <= col_cells) {
                 // one round of n_chunks <= wave slots chunks of chunk x cell rows, + 12 row-times per segment (1 + chunk / col_cells of them)
                 const uint64_t simds = (uint64_t)(cu_count > 0 ? cu_count : 256) * 4;
@@ -1597,6 +1628,23 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
             if (take) {
                 g.chunk_cells = (uint32_t)chunk;
                 g.n_chunks = (uint32_t)n_chunks;
+                // The phase of the chunks (work_setup()): neighbouring strip columns of an image are C mod c cell rows out of step in the plain list.
+                // T images are interleaved column by column, T (C mod c) as close to a multiple of c as an interleave of up to a quarter of what one
+                // XCD walks at a time allows (neighbours, T list positions apart, must mostly stay on one XCD); the smallest such T.  Tuning variant
+                // 7 forces the plain list (round 5), 100 + T any interleave (measurement aids: tools/phase_ab.sh).
+                const uint64_t d = col_cells % chunk;
+                uint32_t best_t = 1;
+                if (d != 0) {
+                    const uint64_t per_xcd = (n_chunks / g.xcds) * chunk / col_cells;      // list positions (columns) one XCD holds at a time
+                    const uint64_t t_max = std::min<uint64_t>(std::min<uint64_t>(count, 64), std::max<uint64_t>(per_xcd / 4, 1));
+                    uint64_t best_dist = std::min(d, chunk - d);
+                    for (uint64_t t = 2; t <= t_max; ++t) {
+                        const uint64_t r = (t * d) % chunk, dist = std::min(r, chunk - r);
+                        if (dist < best_dist) { best_dist = dist; best_t = (uint32_t)t; }
+                    }
+                }
+                g.bal_stride = variant == 7 ? 1u : variant >= 100 ? std::min<uint32_t>((uint32_t)variant - 100u, count) : best_t;
+                if (g.bal_stride < 1) g.bal_stride = 1;
             }
         }
     }
@@ -1646,6 +1694,8 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.col_cells = geo.y_end > geo.y_begin ? (geo.y_end - geo.y_begin + geo.cell_rows - 1) / geo.cell_rows : 0;
     ka.chunk_cells = geo.chunk_cells;
     ka.n_chunks = geo.n_chunks;
+    ka.bal_stride = geo.bal_stride >= 1 ? geo.bal_stride : 1u;
+    ka.xcds = geo.xcds >= 1 ? geo.xcds : 8u;
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;

@@ -337,7 +337,7 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     lib = ssim_amd.load_library()
     assert lib.rmgr_ssim_hip_get_plan(None, 4, 4, 1, None) == errno.EINVAL
     # the struct carries its size: a client compiled against a SHORTER Plan gets its fields and not a byte more
-    assert lib.rmgr_ssim_hip_get_abi_version() == ssim_amd.ABI_VERSION == 5
+    assert lib.rmgr_ssim_hip_get_abi_version() == ssim_amd.ABI_VERSION == 6
     buf = (ctypes.c_uint32 * 16)(*([0xDEADBEEF] * 16))
     buf[0] = 24                                                         # RMGR_SSIM_HIP_PLAN_MIN_SIZE: structSize .. wavefronts
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0

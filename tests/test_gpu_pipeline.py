@@ -212,9 +212,10 @@ def test_balanced_schedule_equals_the_strips(gpu_ctx, shape):
         for mode in (ssim_amd.MODE_EXACT, ssim_amd.MODE_UNFUSED, ssim_amd.MODE_FAST, ssim_amd.MODE_SEPARABLE):
             gpu_ctx.set_mode(mode)
             res = {}
-            for variant, rows in ((2, 0), (3, 0), (6, 0), (0, 0), (6, 64), (2, 8)):
+            # 6: the balanced schedule with plan()'s interleave of the images in the chunk list; 7: the plain list (round 5); 100 + T: T images interleaved
+            for variant, rows in ((2, 0), (3, 0), (6, 0), (7, 0), (102, 0), (105, 0), (164, 0), (0, 0), (6, 64), (103, 64), (2, 8)):
                 gpu_ctx.set_tuning(rows, variant)
-                if variant == 6:
+                if variant in (6, 7) or variant >= 100:
                     chunks = ssim_amd.get_plan(w, h, n, gpu_ctx).balancedChunks
                     assert (chunks == 0) if mode == ssim_amd.MODE_SEPARABLE else (chunks > 0), "the shape is meant to engage the balanced schedule"
                 sums.upload(np.zeros(n))

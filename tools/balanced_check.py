@@ -1,4 +1,4 @@
-"""The balanced schedule (tuning variant 6) against the strips (variants 2, 3): per-image fp64 sums of batches without a map, bit for bit,
+"""The balanced schedule (tuning variants 6 and 7: a chunk's segments last to first / in list order) against the strips (variants 2, 3): per-image fp64 sums of batches without a map, bit for bit,
 over sizes (ragged, shorter than a cell, many cells, power-of-two sizes where plan() takes the chunks by default; 18 fixed + 24 random shapes),
 batch sizes, the four fp32 modes and strip heights.  Run on the GPU box."""
 import sys, numpy as np
@@ -28,7 +28,7 @@ for (w, h, n) in shapes:
     for mode in (0, 3, 1, 4):
         ctx.set_mode(mode)
         res = {}
-        for v in (2, 3, 6, 0):
+        for v in (2, 3, 6, 7, 102, 103, 109, 140, 0):
             for rows in (0, 8, 64):
                 ctx.set_tuning(rows, v)
                 ds.upload(np.zeros(n, np.float64))

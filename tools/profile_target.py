@@ -2,8 +2,9 @@
 """Minimal torch-free workload for rocprofv3 counter passes: the bench.py batch (N distinct 4096^2
 pairs resident in HBM, global SSIM only, or with the map) enqueued K times through the C ABI.
 
-usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width] [rgb=0] [variant=0]
+usage: python3 tools/profile_target.py [pairs=8] [steps=5] [mode=0] [map=0] [width=4096] [height=width] [rgb=0] [variant=0[,variant...]]
 rgb=1: every pair is an interleaved RGB image pair (step 3) and all three channels go into the launch (3 x pairs results)
+variant: a comma-separated list runs `steps` launches of each tuning variant in turn (the counter rows of one rocprofv3 pass, in dispatch order)
 """
 import os
 import sys
@@ -22,7 +23,7 @@ def main():
     h = arg(6, w)
     rgb = arg(7, 0)
     ctx = ssim_amd.Context(0, mode=mode)
-    ctx.set_tuning(0, arg(8, 0))
+    variants = [int(v) for v in (sys.argv[8] if len(sys.argv) > 8 else "0").split(",")]
     n = pairs * (3 if rgb else 1)
     params = (ssim_amd.Params * n)()
     keep = []
@@ -43,9 +44,11 @@ def main():
         params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w, dm.ptr if dm else None, 1, w)
     pairs = n
     sums = ctx.alloc(8 * pairs)
-    for _ in range(steps):
-        ctx.enqueue_batch(params, pairs, sums.ptr)
-    ctx.synchronize()
+    for v in variants:
+        ctx.set_tuning(0, v)
+        for _ in range(steps):
+            ctx.enqueue_batch(params, pairs, sums.ptr)
+        ctx.synchronize()
     res = ssim_amd.finalize(sums.download(np.float64, (pairs,)), w, h)
     print("pairs %d steps %d mode %d map %d size %dx%d: ssim[0] = %.9f (0x%08x)" % (pairs, steps, mode, want_map, w, h, res[0], res[0].view(np.uint32)))
     ctx.close()
