@@ -346,13 +346,15 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == errno.EINVAL
     buf[0] = 64                                                         # a client from the future: only what this library knows is written
     assert lib.rmgr_ssim_hip_get_plan(None, 4096, 4096, 1, ctypes.cast(buf, ctypes.POINTER(ssim_amd.Plan))) == 0
-    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 2048 and buf[12] == 64 and all(v == 0xDEADBEEF for v in buf[13:])      # balancedChunks, balancedChunkRows: a single 4096^2 pair runs the chunks
+    assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 2048 and buf[12] == 64 and buf[13] == 1 and all(v == 0xDEADBEEF for v in buf[14:])      # balancedChunks, balancedChunkRows, balancedInterleave: a single 4096^2 pair runs the chunks (which are strips there: no interleave)
     p = ssim_amd.get_plan(1920, 1080, 1)
     assert (p.cellRows, p.cellsX, p.cellsY) == (8, 30, 135)
     # round 5: the balanced schedule (one round of equal chunks instead of strips) is the default exactly where the strips leave a
     # partial round worth recovering (profiles/r05_balanced_sweep.txt): configs[3]'s per-GPU share yes, the headline batch no
     p = ssim_amd.get_plan(1920, 1080, 128)
     assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (3840, 2041, 1016)      # strips of 544 rows (reported; the launch runs the chunks)
+    # round 6: 16 images interleaved column by column in the chunk list -- 16 x (135 mod 127) = 128 = 127 + 1: neighbouring strip columns one cell row out of step instead of eight (profiles/r06_phase_ab.txt)
+    assert p.balancedInterleave == 16 and ssim_amd.get_plan(1920, 1080, 32).balancedInterleave == 9 and ssim_amd.get_plan(4096, 4096, 32).balancedInterleave == 1
     assert p.balancedChunks * p.balancedChunkRows >= 128 * 15 * 1080            # the chunks cover every row of every strip column
     for (w, h, n) in [(4096, 4096, 24), (4096, 4096, 128), (1920, 1080, 1024), (1920, 1080, 256), (1920, 1080, 1), (256, 256, 1)]:
         assert ssim_amd.get_plan(w, h, n).balancedChunks == 0, (w, h, n)
