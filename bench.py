@@ -753,6 +753,7 @@ def main():
         dts = (time.perf_counter() - t1) / 20
         # the unchanged reference call: HOST pointers, pageable memory, PCIe staging included
         ha, hb = imgs[0][0].cpu().numpy(), imgs[0][1].cpu().numpy()
+        ha_keep, hb_keep = ha, hb
         hv, _ = ssim_amd.compute_ssim(ha, hb)
         if args.mode == 0:
             assert int(hv.view(np.uint32)) == kats[0]
@@ -811,6 +812,31 @@ def main():
             single["concurrent_callers_note"] = ("N host threads looping the unchanged rmgr_ssim_compute_ssim WITH the map on pageable memory, each call on a leased default "
                                                  "context; 4096^2 + map moves 33.5 MB in and 67 MB out per call: at the ~56 GB/s a pageable copy attains on this link one "
                                                  "direction alone caps the call rate near 14 k Mpix/s, so one thread already sits at ~75 % of it")
+        # --- one process, every visible device (rmgr_ssim_hip_compute_ssim_batch_host_devices: a worker thread + context per device, the host batch sharded
+        #     by image, no exchange step in one address space).  Silent on a one-GPU box; on the driver's 8-GPU node its N = 1 line then carries BOTH multi-GPU
+        #     forms: this leg and, in the N = 2, 4, 8 lines, one process per GPU + RCCL.  Host pointers: PCIe staging included, never `value`.
+        #     $SSIM_BENCH_FORCE_DEVICES="0,0" lets a one-GPU box exercise the leg (several contexts on one device). ---
+        forced = os.environ.get("SSIM_BENCH_FORCE_DEVICES")
+        devs = [int(x) for x in forced.split(",")] if forced else list(range(torch.cuda.device_count()))
+        if world == 1 and len(devs) >= 2:
+            per_dev = max(2, min(8, (256 << 20) // (2 * W * H)))
+            hp = [(ha_keep, hb_keep)] * (per_dev * len(devs))
+            one = ssim_amd.compute_ssim_batch_devices(hp[:per_dev], devs[:1], args.mode)
+            t1 = time.perf_counter()
+            one = ssim_amd.compute_ssim_batch_devices(hp[:per_dev], devs[:1], args.mode)
+            dt_one = time.perf_counter() - t1
+            allv = ssim_amd.compute_ssim_batch_devices(hp, devs, args.mode)
+            t1 = time.perf_counter()
+            allv = ssim_amd.compute_ssim_batch_devices(hp, devs, args.mode)
+            dt_all = time.perf_counter() - t1
+            if not (np.all(allv.view(np.uint32) == one.view(np.uint32)[0]) and (args.mode != 0 or int(one.view(np.uint32)[0]) == kats[0])):
+                raise SystemExit("single_process_devices: the devices disagree: %r" % [hex(int(x)) for x in allv.view(np.uint32)])
+            single["single_process_devices"] = {
+                "devices": devs, "forced": bool(forced), "pairs_per_device": per_dev, "pairs": len(hp),
+                "one_device_mpix_s": round(per_dev * W * H / dt_one / 1e6, 1), "all_devices_mpix_s": round(len(hp) * W * H / dt_all / 1e6, 1),
+                "speedup_vs_one_device": round((len(hp) / dt_all) / (per_dev / dt_one), 3),
+                "note": "rmgr_ssim_hip_compute_ssim_batch_host_devices from ONE process: host-resident pairs (pageable memory, PCIe staging pipelined per device) sharded by image over "
+                        "the devices, one worker thread + context each; every result bit-identical to the one-device call; second of two calls timed"}
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)      # restore the slice for consistency
         torch.cuda.synchronize()
 
@@ -829,6 +855,21 @@ def main():
         configs["1080p x128 separable"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "1080p separable", 1920, 1080, 128, False, 4, WORKLOADS["1080p"][5], ksteps)
         configs["4k double + map"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "4k double", 4096, 4096, 4, True, 2, WORKLOADS["4k"][5], ksteps)
         configs["4k x1 exact"] = time_config(torch, np, ssim_amd, synth, ctx, dev, "4k single", 4096, 4096, 1, False, 0, WORKLOADS["4k"][5], 50)
+
+    # --- plan_regret: is the untuned default plan the best of its candidates on THIS box?  rmgr_ssim_hip_tune on a context of its own (the timed
+    #     context above ran, and stays on, the untuned default): kernel time of the default plan / of the best candidate, candidates interleaved ---
+    plan_regret = {}
+    if rank == 0 and world == 1 and not args.no_configs and args.variant == 0 and args.strip_rows == 0:
+        with ssim_amd.Context(dev_index, ctypes.c_void_p(stream.cuda_stream), mode=args.mode) as tctx:
+            for key, (tw, th, tn, tmap) in (("headline", (W, H, mine, want_map)), ("1080p x128", (1920, 1080, 128, False)), ("8k-map x2", (8192, 8192, 2, True)), ("4k x1", (4096, 4096, 1, False))):
+                if not tn:
+                    continue
+                r = tctx.tune(tw, th, tn, tmap)
+                plan_regret[key] = {"workload": "%d x %dx%d%s" % (tn, tw, th, " + map" if tmap else ""), "default_ms": round(r["default_ms"], 4), "best_ms": round(r["best_ms"], 4),
+                                    "regret": round(r["default_ms"] / r["best_ms"], 4), "best": "default" if r["best"] == (0, 0) else "variant %d, strip rows %d" % r["best"],
+                                    "candidates": [{"variant": v, "strip_rows": rr, "ms": round(ms, 4)} for v, rr, ms in r["candidates"]]}
+        plan_regret["note"] = ("rmgr_ssim_hip_tune in this process: the candidate plans plan() chooses between (candidates[0] = the untuned default the timed steps ran), interleaved over three "
+                               "rounds on synthetic pairs of the shape; regret = default / best kernel time (1.0: the default is the best; a candidate replaces it only beyond 0.5 %)")
 
     attainable = None
     if rank == 0:
@@ -870,6 +911,7 @@ def main():
             "fast_mode": other.get("fast_mode", {}),
             "separable_mode": other.get("separable_mode", {}),
             "configs": configs,
+            "plan_regret": plan_regret,
             "device": ctx.describe(),
         }
         if shared_device:

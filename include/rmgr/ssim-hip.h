@@ -150,6 +150,35 @@ typedef struct rmgr_ssim_hip_Plan
 rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_ssim_hip_Plan* plan) RMGR_NOEXCEPT;
 
 /*
+ * The plan of one launch shape, MEASURED.  rmgr_ssim_hip_get_plan reports the library's untuned default -- a model of how strips and chunks pack
+ * onto the device, fitted on 256-CU MI355X boxes; rmgr_ssim_hip_tune times the candidates that model chooses between (the default; the strips at
+ * the default height with the row sums in the blur phase / a phase early; half and twice the strip height; the balanced schedule where it
+ * exists; the one-column kernel for small launches) on the context's own device, under the context's arithmetic mode, on synthetic pairs of
+ * the shape it allocates and frees itself (distinct images up to ~1.5 GB; withMap: dense float maps), candidates interleaved over three rounds,
+ * and keeps the winner for this context's later launches of exactly that shape (width, height, count, map or not, mode) while the context is
+ * on its default tuning (set_tuning(ctx, 0, 0)); a winner has to beat the default by more than 0.5 %.  Results never depend on the choice.
+ * Blocking (a few dozen launches of the shape).  The reference's counterpart is a caller choosing its thread count (include/rmgr/ssim.h:528-533).
+ * result (may be NULL): the caller sets structSize; candidateXxx[0] is the default plan.  rmgr_ssim_hip_clear_tuned forgets every choice.
+ */
+#define RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES 8
+typedef struct rmgr_ssim_hip_TuneResult
+{
+    rmgr_uint32_t structSize;        /* in: sizeof(rmgr_ssim_hip_TuneResult) as the CALLER was compiled */
+    rmgr_uint32_t candidates;        /* plans timed (<= RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES) */
+    rmgr_int32_t  bestVariant;       /* the winner as rmgr_ssim_hip_set_tuning arguments (0 / 0: the default stays) */
+    rmgr_uint32_t bestStripRows;
+    double        defaultMs, bestMs; /* kernel time of the default plan and of the winner: median over rounds of the mean of three launches */
+    /* -- RMGR_SSIM_HIP_TUNE_RESULT_MIN_SIZE ends here -- */
+    rmgr_int32_t  candidateVariant[RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES];
+    rmgr_uint32_t candidateStripRows[RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES];
+    double        candidateMs[RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES];
+} rmgr_ssim_hip_TuneResult;
+#define RMGR_SSIM_HIP_TUNE_RESULT_MIN_SIZE 32u
+rmgr_int32_t rmgr_ssim_hip_tune(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_int32_t withMap,
+                                rmgr_ssim_hip_TuneResult* result) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_clear_tuned(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+
+/*
  * compute_ssim() on HOST pointers: stages both images to HBM, runs the kernels, copies the map
  * back (any ssimStep/ssimStride), returns the global SSIM.  Validation and return codes are the
  * reference's (src/ssim.cpp:962-978).  ctx may be NULL: the call then runs on one of the process-wide DEFAULT contexts

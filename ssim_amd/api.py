@@ -50,6 +50,12 @@ class Plan(ctypes.Structure):
                 ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32), ("balancedInterleave", ctypes.c_uint32)]
 
 
+class TuneResult(ctypes.Structure):
+    _fields_ = [("structSize", ctypes.c_uint32), ("candidates", ctypes.c_uint32), ("bestVariant", ctypes.c_int32), ("bestStripRows", ctypes.c_uint32),
+                ("defaultMs", ctypes.c_double), ("bestMs", ctypes.c_double),
+                ("candidateVariant", ctypes.c_int32 * 8), ("candidateStripRows", ctypes.c_uint32 * 8), ("candidateMs", ctypes.c_double * 8)]
+
+
 ABI_VERSION = 6      # RMGR_SSIM_HIP_ABI_VERSION of include/rmgr/ssim-hip.h this binding was written against
 
 
@@ -79,6 +85,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool", "rmgr_ssim_hip_get_kernel_source_id",
     "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells", "rmgr_ssim_hip_probe_valu",
     "rmgr_ssim_hip_trim", "rmgr_ssim_hip_trim_default_pool", "rmgr_ssim_hip_get_default_pool_memory", "rmgr_ssim_hip_get_memory_info",
+    "rmgr_ssim_hip_tune", "rmgr_ssim_hip_clear_tuned",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -142,6 +149,8 @@ def load_library(path=None):
         "rmgr_ssim_hip_reduce_cells": [vp, u32, u32, u32, vp, vp],
         "rmgr_ssim_hip_probe_valu": [vp, i32, i32, i32, ctypes.POINTER(ctypes.c_double)],
         "rmgr_ssim_hip_trim": [vp],
+        "rmgr_ssim_hip_tune": [vp, u32, u32, u32, i32, ctypes.POINTER(TuneResult)],
+        "rmgr_ssim_hip_clear_tuned": [vp],
         "rmgr_ssim_hip_trim_default_pool": [],
         "rmgr_ssim_hip_get_default_pool_memory": [ctypes.POINTER(ctypes.c_uint64)] * 3,
         "rmgr_ssim_hip_get_memory_info": [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
@@ -381,6 +390,18 @@ class Context(object):
 
     def set_mode(self, mode):
         _check("rmgr_ssim_hip_set_mode", self.lib.rmgr_ssim_hip_set_mode(self.handle, mode))
+
+    def tune(self, width, height, count, with_map=False):
+        """Times the candidate plans of this launch shape on the device and keeps the winner for this context (rmgr_ssim_hip_tune).
+        Returns {"default_ms", "best_ms", "best": (variant, strip_rows), "candidates": [(variant, strip_rows, ms), ...]} (candidates[0]: the default)."""
+        r = TuneResult()
+        r.structSize = ctypes.sizeof(TuneResult)
+        _check("rmgr_ssim_hip_tune", self.lib.rmgr_ssim_hip_tune(self.handle, width, height, count, 1 if with_map else 0, ctypes.byref(r)))
+        return {"default_ms": r.defaultMs, "best_ms": r.bestMs, "best": (r.bestVariant, r.bestStripRows),
+                "candidates": [(r.candidateVariant[i], r.candidateStripRows[i], r.candidateMs[i]) for i in range(min(r.candidates, 8))]}
+
+    def clear_tuned(self):
+        _check("rmgr_ssim_hip_clear_tuned", self.lib.rmgr_ssim_hip_clear_tuned(self.handle))
 
     def trim(self):
         """Gives the context's grow-only staging back to the system (rmgr_ssim_hip_trim)."""

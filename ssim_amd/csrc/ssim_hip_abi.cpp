@@ -86,6 +86,10 @@ struct rmgr_ssim_hip_Context_ {
     bool       comm_nonblocking;   // created with ncclCommInitRankConfig(blocking = 0): calls may report "in progress"
     int        comm_ranks;         // ncclCommCount of the communicator
 
+    // rmgr_ssim_hip_tune: the measured choice per launch shape, consulted by enqueue() while the context is on its default tuning
+    struct Tuned { uint32_t width, height, count; int mode; bool map; int variant, strip_rows; };
+    std::vector<Tuned> tuned;
+
     char describe[256];
     std::mutex lock;
 };
@@ -261,13 +265,19 @@ int upload_descs(rmgr_ssim_hip_Context* c, const PairDesc* descs, uint32_t count
 int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t count, const PairDesc* descs, bool any_map, double* sums_dev,
             uint32_t y_begin = 0, uint32_t y_rows = 0xFFFFFFFFu, bool reduce = true, double* cells_out = NULL)
 {
-    int variant = c->variant;
-    if (variant == 0 && c->strip_rows == 0) variant = ssim_hip::default_variant(width, height, count, c->mode, c->cu_count);
+    int variant = c->variant, strip_rows = c->strip_rows;
+    if (variant == 0 && strip_rows == 0 && y_begin == 0 && y_rows == 0xFFFFFFFFu && !cells_out) {      // default tuning, whole images: a measured choice, if one was made
+        for (size_t i = 0; i < c->tuned.size(); ++i) {
+            const rmgr_ssim_hip_Context_::Tuned& t = c->tuned[i];
+            if (t.width == width && t.height == height && t.count == count && t.mode == c->mode && t.map == any_map) { variant = t.variant; strip_rows = t.strip_rows; break; }
+        }
+    }
+    if (variant == 0 && strip_rows == 0) variant = ssim_hip::default_variant(width, height, count, c->mode, c->cu_count);
     bool all_fit = true;
     for (uint32_t i = 0; i < count && all_fit; ++i)
         all_fit = ssim_hip::fits_strip2(descs[i], width, height);
     if (!all_fit) variant = 1;
-    ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, c->strip_rows, variant, c->cu_count, c->xcd_count, y_begin, y_rows);
+    ssim_hip::Geometry geo = ssim_hip::plan(width, height, count, c->mode, strip_rows, variant, c->cu_count, c->xcd_count, y_begin, y_rows);
     geo.wide = !all_fit;                             // the 64-bit form of the one-column kernel only where it is needed
     geo.map_unit = any_map && (width & 1u) == 0;     // the 8-byte map stores of the two-column kernel (ssim_kernels.hip, MAP == 2)
     for (uint32_t i = 0; i < count && geo.map_unit; ++i)
@@ -2055,6 +2065,159 @@ rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* c, rmgr_uint64_t* 
     if (kernelMs) *kernelMs = c->prof_ms;
     c->prof_launches = 0;
     c->prof_ms = 0.0;
+    return 0;
+}
+
+// ---- rmgr_ssim_hip_tune: the plan for one launch shape, MEASURED on the device the context runs on ---------------------------------------------
+// plan()'s default is a model fitted on 256-CU boxes that differ by +-4 % (strip height by a packing model, EARLY by launch length, the balanced
+// schedule by a priced rule); this times the handful of candidates that model chooses between -- on THIS device, at THIS clock -- and keeps the
+// winner for later launches of the shape.  Candidates: the default; the two-column strips at the default height with the row sums in the blur
+// phase / EARLY; the default kernel at half and at twice the strip height; the balanced schedule (no map; modes 0, 3, 1); the one-column kernel for
+// small launches.  Every candidate gives the same bits (cells at absolute positions, fixed-order reduction): only time is at stake.
+namespace {
+
+struct TuneCandidate { int variant, rows; double ms; uint64_t key; };
+
+uint64_t plan_key(const ssim_hip::Geometry& g, bool early, int one_column)
+{
+    uint64_t k = g.strip_w;
+    k = k * 1000003u + g.strip_rows; k = k * 1000003u + g.n_chunks; k = k * 1000003u + g.chunk_cells; k = k * 1000003u + g.bal_stride;
+    return (k * 4 + (early ? 1 : 0)) * 2 + (uint64_t)one_column;
+}
+
+} // namespace
+
+rmgr_int32_t rmgr_ssim_hip_tune(rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_int32_t withMap,
+                                rmgr_ssim_hip_TuneResult* result) RMGR_NOEXCEPT
+{
+    if (!c || width == 0 || height == 0 || count == 0 || count > 65535u) return EINVAL;
+    if (result && result->structSize < RMGR_SSIM_HIP_TUNE_RESULT_MIN_SIZE) return EINVAL;
+    USE_DEVICE(c);
+    const bool map = withMap != 0;
+    const int mode = c->mode;
+    // forget an earlier choice for this shape: the default candidate must run the default
+    for (size_t i = 0; i < c->tuned.size(); ++i)
+        if (c->tuned[i].width == width && c->tuned[i].height == height && c->tuned[i].count == count && c->tuned[i].mode == mode && c->tuned[i].map == map) { c->tuned.erase(c->tuned.begin() + i); break; }
+
+    // candidates, de-duplicated by the launch they produce
+    const int v0 = ssim_hip::default_variant(width, height, count, mode, c->cu_count);
+    const ssim_hip::Geometry g0 = ssim_hip::plan(width, height, count, mode, 0, v0, c->cu_count, c->xcd_count);
+    const uint32_t cell = g0.cell_rows, R = g0.strip_rows;
+    std::vector<TuneCandidate> cand;
+    try {
+        struct Add {
+            static void one(std::vector<TuneCandidate>& list, rmgr_ssim_hip_Context* c, uint32_t w, uint32_t h, uint32_t n, bool map, int variant, int rows)
+            {
+                int v = variant;
+                if (v == 0 && rows == 0) v = ssim_hip::default_variant(w, h, n, c->mode, c->cu_count);
+                ssim_hip::Geometry g = ssim_hip::plan(w, h, n, c->mode, rows, v, c->cu_count, c->xcd_count);
+                if (map) { g.chunk_cells = 0; g.n_chunks = 0; g.bal_stride = 1; }                   // launches with a map run the strips
+                if (ssim_hip::is_balanced_variant(variant) && g.n_chunks == 0) return;             // no balanced form for this launch
+                const bool one = c->mode == RMGR_SSIM_HIP_MODE_DOUBLE || v == 1;
+                const TuneCandidate t = {variant, rows, 0.0, plan_key(g, g.n_chunks ? true : ssim_hip::uses_early_row_sums(g, c->mode, v), one ? 1 : 0)};
+                for (size_t i = 0; i < list.size(); ++i) if (list[i].key == t.key) return;
+                list.push_back(t);
+            }
+        };
+        Add::one(cand, c, width, height, count, map, 0, 0);                                        // the default, first
+        if (mode != RMGR_SSIM_HIP_MODE_DOUBLE) {
+            Add::one(cand, c, width, height, count, map, 2, (int)R);
+            if (mode == RMGR_SSIM_HIP_MODE_EXACT || mode == RMGR_SSIM_HIP_MODE_UNFUSED) Add::one(cand, c, width, height, count, map, 3, (int)R);
+            if (!map) Add::one(cand, c, width, height, count, map, 6, 0);
+            if ((uint64_t)width * height * count <= (uint64_t(1) << 22)) Add::one(cand, c, width, height, count, map, 1, 0);
+        }
+        const uint32_t half = std::max(cell, ((R / 2) + cell - 1) & ~(cell - 1)), twice = std::min<uint32_t>(2 * R, (height + cell - 1) & ~(cell - 1));
+        const int keep = (mode == RMGR_SSIM_HIP_MODE_DOUBLE) ? 0 : (g0.strip_w == 64 ? 1 : ssim_hip::uses_early_row_sums(g0, mode, v0) ? 3 : 2);
+        if (half != R) Add::one(cand, c, width, height, count, map, keep, (int)half);
+        if (twice != R) Add::one(cand, c, width, height, count, map, keep, (int)twice);
+    } catch (...) { return ENOMEM; }
+
+    // synthetic pairs of the shape (SURVEY.md 8(d) pattern): distinct images up to ~1.5 GB, then the descriptors cycle through them
+    const size_t plane = (size_t)width * height, per_pair = 2 * plane + (map ? 4 * plane : 0);
+    const uint32_t distinct = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(count, (uint64_t(3) << 29) / per_pair));
+    uint8_t* images = NULL;
+    float* maps = NULL;
+    double* sums = NULL;
+    PairDesc* descs = new (std::nothrow) PairDesc[count];
+    if (!descs) return ENOMEM;
+    struct Cleanup {
+        uint8_t*& images; float*& maps; double*& sums; PairDesc* descs;
+        ~Cleanup() { if (images) (void)hipFree(images); if (maps) (void)hipFree(maps); if (sums) (void)hipFree(sums); delete[] descs; (void)hipGetLastError(); }
+    } cleanup = {images, maps, sums, descs};
+    (void)cleanup;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&images), 2 * plane * distinct));
+    if (map) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&maps), sizeof(float) * plane * distinct));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sums), sizeof(double) * count));
+    for (uint32_t i = 0; i < distinct; ++i)
+        HIP_TRY(ssim_hip::launch_synth_pair(images + 2 * plane * i, width, images + 2 * plane * i + plane, width, width, height, 0x5EEDull + i, c->stream));
+    for (uint32_t i = 0; i < count; ++i) {
+        const uint32_t k = i % distinct;
+        PairDesc& d = descs[i];
+        d.a = images + 2 * plane * k; d.a_step = 1; d.a_stride = width;
+        d.b = d.a + plane;            d.b_step = 1; d.b_stride = width;
+        d.map = map ? maps + plane * k : NULL; d.map_step = map ? 1 : 0; d.map_stride = map ? (int64_t)width : 0;
+    }
+
+    // timing: rounds of (every candidate: one untimed + three timed launches), candidates interleaved so that clock drift hits all alike; the
+    // figure of a candidate is the median of its per-round means
+    const int saved_rows = c->strip_rows, saved_variant = c->variant;
+    const bool saved_prof = c->profiling;
+    int rc = drain_profile(c);
+    const uint64_t saved_launches = c->prof_launches;
+    const double saved_ms = c->prof_ms;
+    const int rounds = 3, per_round = 3;
+    std::vector<std::vector<double> > samples(cand.size());
+    for (int r = 0; r < rounds && !rc; ++r) {
+        for (size_t k = 0; k < cand.size() && !rc; ++k) {
+            c->strip_rows = cand[k].rows; c->variant = cand[k].variant;
+            c->profiling = false;
+            rc = enqueue(c, width, height, count, descs, map, sums);
+            c->profiling = true;
+            c->prof_launches = 0; c->prof_ms = 0.0;
+            for (int j = 0; j < per_round && !rc; ++j) rc = enqueue(c, width, height, count, descs, map, sums);
+            if (!rc) { const hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { (void)hipGetLastError(); rc = map_hip_error(e); } }
+            if (!rc) rc = drain_profile(c);
+            if (!rc && c->prof_launches) { try { samples[k].push_back(c->prof_ms / (double)c->prof_launches); } catch (...) { rc = ENOMEM; } }
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    c->strip_rows = saved_rows; c->variant = saved_variant; c->profiling = saved_prof;
+    c->prof_launches = saved_launches; c->prof_ms = saved_ms;
+    if (rc) return rc;
+    size_t best = 0;
+    for (size_t k = 0; k < cand.size(); ++k) {
+        if (samples[k].empty()) return ECHILD;
+        std::sort(samples[k].begin(), samples[k].end());
+        cand[k].ms = samples[k][samples[k].size() / 2];
+        if (cand[k].ms < cand[best].ms) best = k;
+    }
+    // a winner must beat the default by more than the measurement's own scatter (0.5 %) to replace it
+    if (best != 0 && cand[best].ms > cand[0].ms * 0.995) best = 0;
+    if (best != 0) {
+        try { const rmgr_ssim_hip_Context_::Tuned t = {width, height, count, mode, map, cand[best].variant, cand[best].rows}; c->tuned.push_back(t); }
+        catch (...) { return ENOMEM; }
+    }
+    if (result) {
+        rmgr_ssim_hip_TuneResult full;
+        memset(&full, 0, sizeof(full));
+        full.structSize = result->structSize;
+        full.candidates = (rmgr_uint32_t)cand.size();
+        full.bestVariant = cand[best].variant;
+        full.bestStripRows = (rmgr_uint32_t)cand[best].rows;
+        full.defaultMs = cand[0].ms;
+        full.bestMs = cand[best].ms;
+        for (size_t k = 0; k < cand.size() && k < RMGR_SSIM_HIP_TUNE_MAX_CANDIDATES; ++k) {
+            full.candidateVariant[k] = cand[k].variant; full.candidateStripRows[k] = (rmgr_uint32_t)cand[k].rows; full.candidateMs[k] = cand[k].ms;
+        }
+        memcpy(result, &full, std::min<size_t>(result->structSize, sizeof(full)));
+    }
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_clear_tuned(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    c->tuned.clear();
     return 0;
 }
 

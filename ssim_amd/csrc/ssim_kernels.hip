@@ -1571,10 +1571,9 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
         // Round 5: strips of the two-wave kernels may be up to 1024 rows tall (512 since round 2: "taller measured no better" then).  Measured on the round-5
         // kernels, 512 / 1024 / 2048 interleaved over 36 shapes (profiles/r05_strip_cap_sweep.txt): 1024 is +1.2 % on 32 and 48 x 4096^2, +1.8 % on 8 x 8192^2
         // (+2.1 % with the map), +0...1.8 % for MODE_FAST, nothing below -1.1 %; 2048 adds a few tenths and loses 2 % on 128 x 4096^2.  The three-wave
-        // kernels keep 512 (MODE_SEPARABLE at 1024 / 2048 rows: -3...-4 %).  The balanced schedule's rule below was calibrated against strips of at
-        // most 512 rows and keeps comparing with those (strips_cost).
+        // kernels keep 512 (MODE_SEPARABLE at 1024 / 2048 rows: -3...-4 %).  (Round 5's balanced rule compared with strips of at most 512 rows; round 6's
+        // compares with the split chosen here.)
         const uint32_t cap = waves >= 3 ? 512u : 1024u;
-        uint64_t best_capped = ~(uint64_t)0;                              // the best split into strips of at most 512 rows
         uint32_t best_rows = round_cell(rows_total < cap ? rows_total : cap);
         const uint32_t ny_min = (rows_total + cap - 1) / cap, ny_max = (rows_total + cr - 1) / cr;
         for (uint32_t ny = ny_min; ny <= ny_max; ++ny) {
@@ -1587,62 +1586,62 @@ Geometry plan(uint32_t width, uint32_t height, uint32_t count, int mode, int str
             const uint64_t last = rem == 0 ? 0 : tail[(rem - 1) / simds];
             const uint64_t cost = u * (full * 1000 + last);
             if (cost < best) { best = cost; best_rows = rows; }
-            if (rows <= 512 && cost < best_capped) best_capped = cost;
         }
         strip_rows = (int)best_rows;
-        strips_cost = best_capped;
+        strips_cost = best;
     }
     if (strip_rows < 1) strip_rows = 1;
     g.strip_rows = round_cell((uint32_t)strip_rows);      // strips start on cell boundaries
     g.strips_y = rows_total ? (rows_total + g.strip_rows - 1) / g.strip_rows : 0;
     // The balanced schedule (work_setup()): the two-waves-per-SIMD two-column kernels (bit-exact modes, MODE_FAST) without a map (launch_strip2() checks the map).  Tuning
-    // variant 6 forces it.  By default it is taken where the packing model prices the strips at least 3.5 % above one round of equal
-    // chunks, a chunk is at most 1100 rows and no longer than a strip column.  (3.5 %: re-fitted late in round 5 on 128 more launch shapes -- 480p ... 8K, odd
-    // sizes, tools/r5_rule_sweep.sh + r5_rule_fit.py, profiles/r05_rule_sweep.txt: between 3.5 and 7 % the chunks gain +1 ... +4 %, e.g. 8 / 12 / 16 x 2160p, 32 x 1080p,
-    // 16 x 5K; below 3.5 % they lose as often as they win; beyond 1100 rows or one column they lose.  The first calibration, at 7 %:)  Measured with strips and chunks interleaved on one box over 32 launch shapes
-    // (profiles/r05_balanced_sweep.txt), the chunks run ~5.5 % slower than this model says (a static equal partition needs every
-    // SIMD to run at the same speed for the whole launch; the strips' later rounds absorb the differences), more for long chunks:
-    // the rule picks 24 / 40 / 48 / 64 / 96 / 128 x 1080p (+4.0 / +5.2 / +5.7 / +4.0 / +1.2 / +2.1 %) and 3 x 4096^2 (+4.8 %), and leaves
-    // alone everything the chunks lose on (8 x 1080p -7 %, 12 / 24 x 4096^2 -3 / -5 %, 192...384 x 1080p -2...-3.5 %) or only tie.
-    // MODE_FAST, same rule, same shapes: +5.1 / +5.4 / +6.6 / +3.8 / +5.5 / +3.4 % and +5.1 %.  MODE_SEPARABLE (three waves per SIMD) LOSES with chunks
-    // nearly everywhere (-1...-17 %; at best +2 %): it keeps its strips and has no balanced instantiation.
+    // variant 6 forces it.  By default it is taken where the packing model prices the best strips at or above one round of equal chunks (a chunk: its rows + 12 row-times
+    // per segment, 1 + chunk / column of them) -- 4 % above where no interleave of the images brings neighbouring strip columns within 16 rows of each other -- and
+    // where a chunk divides the strip column evenly.
+    // History of the rule.  Round 5 fitted it on kernels whose chunk list fetched 2.9...3.0x the algorithmic bytes (neighbouring columns out of step: work_setup()):
+    // the chunks then ran ~5.5 % behind the model, lost beyond 1100 rows and beyond one column per chunk, and the rule asked for 3.5 % and both caps
+    // (profiles/r05_balanced_sweep.txt, r05_rule_sweep.txt).  With the images interleaved (round 6) the chunks run ~2.5 % behind the model and win on long launches as
+    // well: rmgr_ssim_hip_tune over 148 launch shapes, 480p ... 8K, 1 ... 256 pairs (tools/tune_sweep.py, profiles/r06_tune_sweep.txt) found the round-5 rule within 1 % of the
+    // best candidate on 73 % of them (mean regret 1.0105; 192 / 256 x 1080p +5.4 / +3.2 %, 12 x 8192^2 +7.6 %, 64 x 2160p +8.8 %, 32 x 5K +11.7 % left on the table,
+    // all on multi-round strips against one round of chunks).  Re-fitted on that sweep: threshold 0, no caps -- mean regret of the strips-or-chunks choice 1.0072 -> 1.0018.
+    // What the chunks still lose on and the rule leaves alone: launches of a few strips per SIMD (2 x 1080p -17 %, 4 x 1000^2 -13 %: ten warm-up rows per 16...64-row chunk).
+    // MODE_FAST takes the same rule; MODE_SEPARABLE (three waves per SIMD) loses with chunks nearly everywhere (-1...-17 %; at best +2 %) and has no balanced instantiation.
     g.chunk_cells = 0; g.n_chunks = 0; g.bal_stride = 1;
     if ((mode == MODE_EXACT || mode == MODE_UNFUSED || mode == MODE_FAST) && g.strip_w == 128 && rows_total > 0 && (is_balanced_variant(variant) || (variant == 0 && default_rows))) {
         const uint64_t col_cells = (rows_total + cr - 1) / cr, all = (uint64_t)count * g.strips_x * col_cells;
         const uint64_t want = g.wave_slots;
         if (all > want && all < (1ull << 31)) {
             const uint64_t chunk = (all + want - 1) / want, n_chunks = (all + chunk - 1) / chunk;
+            // The phase of the chunks (work_setup()): neighbouring strip columns of an image are C mod c cell rows out of step in the plain list.
+            // T images are interleaved column by column, T (C mod c) as close to a multiple of c as an interleave of up to a quarter of what one
+            // XCD walks at a time allows (neighbours, T list positions apart, must mostly stay on one XCD); the smallest such T.  Tuning variant
+            // 7 forces the plain list (round 5), 100 + T any interleave (measurement aids: tools/phase_ab.sh).
+            const uint64_t d = col_cells % chunk;
+            uint32_t best_t = 1;
+            uint64_t best_dist = 0;
+            if (d != 0) {
+                const uint64_t per_xcd = (n_chunks / g.xcds) * chunk / col_cells;      // list positions (columns) one XCD holds at a time
+                const uint64_t t_max = std::min<uint64_t>(std::min<uint64_t>(count, 64), std::max<uint64_t>(per_xcd / 4, 1));
+                best_dist = std::min(d, chunk - d);
+                for (uint64_t t = 2; t <= t_max; ++t) {
+                    const uint64_t r = (t * d) % chunk, dist = std::min(r, chunk - r);
+                    if (dist < best_dist) { best_dist = dist; best_t = (uint32_t)t; }
+                }
+            }
             bool take = is_balanced_variant(variant);
-            if (!take && strips_cost != 0 && chunk * cr <= 1100 && chunk <= col_cells) {
+            if (!take && strips_cost != 0) {
                 // one round of n_chunks <= wave slots chunks of chunk x cell rows, + 12 row-times per segment (1 + chunk / col_cells of them)
                 const uint64_t simds = (uint64_t)(cu_count > 0 ? cu_count : 256) * 4;
                 const uint64_t tail = n_chunks > simds ? 1000 : 685;
                 const uint64_t chunks_cost = (chunk * cr * col_cells + 12 * (col_cells + chunk)) * tail / col_cells;
-                take = strips_cost * 1000 >= chunks_cost * 1035;
+                take = strips_cost * 1000 >= chunks_cost * (best_dist * cr > 16 ? 1040 : 1000);
             }
             // ... and where a chunk divides the strip column evenly: no chunk straddles two columns, so the chunks ARE strips -- the tallest that fill the
             // wave slots in ONE round, without a seam between rounds (8 ... 64 x 4096^2 +0.5 / +0.7 / +1.1 / +2.3 %, 2 ... 16 x 8192^2 +0.9 ... +2.1 %, 32 / 128 x
-            // 2048^2 +0.8 / +1.2 %; against the shipped strips on 38 shapes: +0.6 ... +2.4 %, single pairs included).  Chunks of several whole columns are left alone: 128 x 4096^2 -2.3 %, 512 x 2048^2 -3.9 %
-            // (profiles/r05_strip_cap_sweep.txt, last section).
+            // 2048^2 +0.8 / +1.2 %; against the shipped strips on 38 shapes: +0.6 ... +2.4 %, single pairs included; profiles/r05_strip_cap_sweep.txt, last section).
             if (!take && strips_cost != 0 && mode != MODE_FAST && col_cells % chunk == 0) take = true;      // MODE_FAST: -0.8 ... +1.0 %, no net gain: left on its strips
             if (take) {
                 g.chunk_cells = (uint32_t)chunk;
                 g.n_chunks = (uint32_t)n_chunks;
-                // The phase of the chunks (work_setup()): neighbouring strip columns of an image are C mod c cell rows out of step in the plain list.
-                // T images are interleaved column by column, T (C mod c) as close to a multiple of c as an interleave of up to a quarter of what one
-                // XCD walks at a time allows (neighbours, T list positions apart, must mostly stay on one XCD); the smallest such T.  Tuning variant
-                // 7 forces the plain list (round 5), 100 + T any interleave (measurement aids: tools/phase_ab.sh).
-                const uint64_t d = col_cells % chunk;
-                uint32_t best_t = 1;
-                if (d != 0) {
-                    const uint64_t per_xcd = (n_chunks / g.xcds) * chunk / col_cells;      // list positions (columns) one XCD holds at a time
-                    const uint64_t t_max = std::min<uint64_t>(std::min<uint64_t>(count, 64), std::max<uint64_t>(per_xcd / 4, 1));
-                    uint64_t best_dist = std::min(d, chunk - d);
-                    for (uint64_t t = 2; t <= t_max; ++t) {
-                        const uint64_t r = (t * d) % chunk, dist = std::min(r, chunk - r);
-                        if (dist < best_dist) { best_dist = dist; best_t = (uint32_t)t; }
-                    }
-                }
                 g.bal_stride = variant == 7 ? 1u : variant >= 100 ? std::min<uint32_t>((uint32_t)variant - 100u, count) : best_t;
                 if (g.bal_stride < 1) g.bal_stride = 1;
             }

@@ -349,14 +349,20 @@ def test_strip_plan_covers_every_image_and_fills_the_gpu():
     assert buf[8] == 32 and buf[9] == 64 and buf[10] == 128 and buf[11] == 2048 and buf[12] == 64 and buf[13] == 1 and all(v == 0xDEADBEEF for v in buf[14:])      # balancedChunks, balancedChunkRows, balancedInterleave: a single 4096^2 pair runs the chunks (which are strips there: no interleave)
     p = ssim_amd.get_plan(1920, 1080, 1)
     assert (p.cellRows, p.cellsX, p.cellsY) == (8, 30, 135)
-    # round 5: the balanced schedule (one round of equal chunks instead of strips) is the default exactly where the strips leave a
-    # partial round worth recovering (profiles/r05_balanced_sweep.txt): configs[3]'s per-GPU share yes, the headline batch no
+    # the balanced schedule (one round of equal chunks instead of strips).  Round 5 took it where its model priced the strips 3.5 % above the chunks, for chunks of
+    # at most 1100 rows and one strip column; round 6 (images interleaved in the chunk list: neighbouring columns in step, profiles/r06_phase_ab.txt) re-fitted the rule on
+    # rmgr_ssim_hip_tune over 148 shapes (profiles/r06_tune_sweep.txt): wherever the model prices the best strips at or above the chunks, long launches included
     p = ssim_amd.get_plan(1920, 1080, 128)
     assert (p.wavefronts, p.balancedChunks, p.balancedChunkRows) == (3840, 2041, 1016)      # strips of 544 rows (reported; the launch runs the chunks)
     # round 6: 16 images interleaved column by column in the chunk list -- 16 x (135 mod 127) = 128 = 127 + 1: neighbouring strip columns one cell row out of step instead of eight (profiles/r06_phase_ab.txt)
     assert p.balancedInterleave == 16 and ssim_amd.get_plan(1920, 1080, 32).balancedInterleave == 9 and ssim_amd.get_plan(4096, 4096, 32).balancedInterleave == 1
     assert p.balancedChunks * p.balancedChunkRows >= 128 * 15 * 1080            # the chunks cover every row of every strip column
-    for (w, h, n) in [(4096, 4096, 24), (4096, 4096, 128), (1920, 1080, 1024), (1920, 1080, 256), (1920, 1080, 1), (256, 256, 1)]:
+    for (w, h, n, chunks, rows, stride) in [(4096, 4096, 24, 2048, 1536, 3), (1920, 1080, 256, 2041, 2032, 32), (8192, 8192, 12, 2048, 3072, 3), (5120, 2880, 32, 2022, 1824, 19)]:
+        p = ssim_amd.get_plan(w, h, n)                                         # what round 5's caps kept on multi-round strips: +3...12 % (profiles/r06_tune_sweep.txt)
+        assert (p.balancedChunks, p.balancedChunkRows, p.balancedInterleave) == (chunks, rows, stride), (w, h, n)
+    # ... and not where a launch is a few short strips per SIMD (ten warm-up rows per 16...64-row chunk: 2 x 1080p -17 %), nor where no interleave brings the
+    # neighbouring columns within 16 rows and the model's margin is below 4 % (16 x 5120x2880: 32-row cells; measured -8 %)
+    for (w, h, n) in [(1920, 1080, 1), (256, 256, 1), (1920, 1080, 2), (1000, 1000, 4), (1920, 1080, 8), (5120, 2880, 16)]:
         assert ssim_amd.get_plan(w, h, n).balancedChunks == 0, (w, h, n)
     # ... and where the chunk divides the strip column evenly (the chunks are then strips: the tallest that fill the wave slots in one round): the headline batch,
     # a single 4096^2 pair, 8192^2 pairs -- +0.6 ... +2.4 % over the strips on every such shape (profiles/r05_strip_cap_sweep.txt)
@@ -545,12 +551,12 @@ def test_comm_entry_points_without_a_device(lib):
 
 def test_plan_invariants_over_random_shapes():
     """rmgr_ssim_hip_get_plan on 3000 random launch shapes (pure host arithmetic): the strips tile the image, start on reduction-cell boundaries and are at most 1024
-    rows tall; a balanced plan's chunks cover every cell row of every strip column exactly once in at most waveSlots wavefronts, and obey the rule they were chosen
-    by (the chunk divides the strip column evenly, or it is at most 1100 rows and no longer than a column)."""
+    rows tall; a balanced plan's chunks cover every cell row of every strip column exactly once in at most waveSlots wavefronts (round 6: of any length -- round 5's
+    caps of 1100 rows and one column per chunk went with the over-fetch they were fitted on), and the interleave of the images is within its bounds."""
     import random
     import ssim_amd
     rnd = random.Random(20261007)
-    taken = even = 0
+    taken = even = long_chunks = 0
     for i in range(3000):
         kind = rnd.randrange(3)
         if kind == 0:
@@ -573,8 +579,12 @@ def test_plan_invariants_over_random_shapes():
             cells = n * p.stripsX * col_cells
             assert cells > p.waveSlots and p.balancedChunks <= p.waveSlots
             assert (p.balancedChunks - 1) * chunk < cells <= p.balancedChunks * chunk          # every cell row of every strip column, once
+            assert 1 <= p.balancedInterleave <= min(n, 64), (w, h, n, p.balancedInterleave)
             if col_cells % chunk == 0:
                 even += 1
-            else:
-                assert p.balancedChunkRows <= 1100 and chunk <= col_cells, (w, h, n, p.balancedChunkRows)
-    assert taken > 300 and even > 100, (taken, even)           # the draw does exercise both ways into the balanced form
+                assert p.balancedInterleave == 1                                                # chunks that ARE strips are in step already
+            elif chunk > col_cells:
+                long_chunks += 1
+        else:
+            assert p.balancedInterleave == 0
+    assert taken > 300 and even > 100 and long_chunks > 20, (taken, even, long_chunks)           # the draw does exercise every way into the balanced form

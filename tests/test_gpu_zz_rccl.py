@@ -58,17 +58,44 @@ def run_selftest_once(args, limit, comm_timeout, extra):
                   % (" ".join(args), r.returncode, r.stdout[-1500:], r.stderr[-6000:]))
 
 
+def environmental_signature(log, limit):
+    """What in a failed attempt's log says that the BOX failed it, not this repository (a blanket retry would also retry away an intermittent
+    hang in the bounded-failure code these tests guard).  None: no such signature -- the failure stands."""
+    import re
+    low = log.lower()
+    for needle in ("address already in use", "eaddrinuse", "cannot assign requested address"):
+        if needle in low:
+            return "a socket of the bootstrap could not be bound (%s)" % needle
+    # the first load of the half-gigabyte librccl: "[rmgr-ssim comm] helper: loading librccl" is followed by "[rmgr-ssim comm] <path> (<seconds> s)" once it is in
+    if "helper: loading librccl" in log:
+        m = re.search(r"\[rmgr-ssim comm\] (?!helper:)\S.*?\((\d+\.\d+) s\)", log)
+        if m is None:
+            return "the attempt ended while librccl was still being loaded (cold disk image)"
+        if float(m.group(1)) > 0.4 * limit:
+            return "loading librccl took %s s of the attempt's %d" % (m.group(1), limit)
+    stages = re.findall(r"\[rccl_selftest\s+([0-9.]+) s\] (.*)", log)
+    if stages and stages[-1][1].startswith("import "):
+        return "the attempt ended inside `%s` (first import on a fresh box)" % stages[-1][1]
+    return None
+
+
 def run_selftest(*args, limit=50, comm_timeout=None, extra=0):
-    """One child process per attempt, at most two attempts: what these tests exercise is a bootstrap over sockets and a first load of a very
-    large library on a box nobody has used before -- a first attempt that dies of the BOX (cold pages, a port still in TIME_WAIT) says nothing
-    about this repository, a second one that fails as well does, and carries both logs."""
+    """One child process per attempt.  A SECOND attempt is made only when the first one's log carries an environmental signature -- a bootstrap
+    socket that could not be bound, the first load of librccl from a cold disk image eating the limit, a first `import torch` -- and every such
+    retry is reported as a warning, which pytest counts in its summary line.  Any other failure (a deadline that did not fire, a wrong errno, a hang
+    in the abort path) fails at once with the attempt's stage markers and RCCL log."""
+    import warnings
     warm_library_pages()
     r, why = run_selftest_once(args, limit, comm_timeout, extra)
     if r is None:
+        sig = environmental_signature(why, limit)
+        if sig is None:
+            pytest.fail("no environmental signature in the log: not retried.\n%s" % why)
         r, why2 = run_selftest_once(args, limit, comm_timeout, extra)
         if r is None:
-            pytest.fail("two attempts failed.\n===== first attempt\n%s\n===== second attempt\n%s" % (why, why2))
-        print("rccl_selftest %s: the first attempt failed, the second passed.  First attempt:\n%s" % (" ".join(args), why[-3000:]))
+            pytest.fail("two attempts failed (the first: %s).\n===== first attempt\n%s\n===== second attempt\n%s" % (sig, why, why2))
+        warnings.warn(UserWarning("rccl_selftest %s: RETRIED once -- %s; the second attempt passed" % (" ".join(args), sig)))
+        print("rccl_selftest %s: the first attempt failed (%s), the second passed.  First attempt:\n%s" % (" ".join(args), sig, why[-3000:]))
     return r
 
 
@@ -139,3 +166,29 @@ def test_bench_two_ranks_on_one_device_over_gloo():
     assert "pairs [0, 3)" in ex["per_rank"][0] and "pairs [3, 6)" in ex["per_rank"][1]
     assert [r["rank"] for r in ex["per_rank_ms"]] == [0, 1] and all(r["kernel_avg_ms"] > 0 and r["ms_per_step"] >= r["kernel_avg_ms"] for r in ex["per_rank_ms"])
     assert line["ms_per_step"] >= max(r["ms_per_step"] for r in ex["per_rank_ms"]) - 1e-3          # the line reports the slowest rank
+
+
+def test_bench_eight_ranks_configs3_strong_on_one_device_over_gloo():
+    """BASELINE.json configs[3] exactly -- 1024 x 1080p split strongly over EIGHT ranks, 128 pairs each, `--workload 1080p --scaling strong` as the
+    driver will launch it on an 8-GPU box -- run functionally on the 1-GPU box: eight ranks on device 0, gloo as the carrier (a test mode; the
+    line says so and is not a scaling result).  Every rank owns its block of 128 pairs, the known-answer gate passes on the rank that owns the
+    first seeds, all eight ranks hold the same digest of the exchanged 1024-entry result vector, rank 0 prints ONE line."""
+    import json
+    env = dict(os.environ, SSIM_BENCH_SHARED_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", RMGR_SSIM_HIP_COMM_TIMEOUT_S="20")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29549",
+           os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "1080p", "--scaling", "strong", "--sustain", "0", "--no-configs",
+           "--no-cold-start", "--no-cpu-baseline", "--exchange", "torch"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and "test_mode" in line and line["value"] > 0
+    assert line["config"]["name"] == "1080p" and line["config"]["pairs_total"] == 1024 and line["config"]["pairs_per_gpu"] == 128
+    ex = line["exchange"]
+    assert ex["ranks_seen"] == 8 and len(ex["per_rank"]) == 8 and ex["carrier"] == "torch"
+    digests = [l.rsplit("digest ", 1)[1] for l in ex["per_rank"]]
+    assert len(set(digests)) == 1 and digests[0] == line["config"]["results_digest"]
+    for k in range(8):
+        assert "pairs [%d, %d)" % (128 * k, 128 * (k + 1)) in ex["per_rank"][k], ex["per_rank"][k]
+    assert [x["rank"] for x in ex["per_rank_ms"]] == list(range(8))
