@@ -329,22 +329,38 @@ class Batch(object):
             self.params[i] = ssim_amd.make_params(w, h, a.data_ptr(), 1, w, b.data_ptr(), 1, w, m.data_ptr() if want_map else None, 1, w)
 
 
+PEAK_LANE_OPS_PER_CLOCK = 32768.0      # 256 CUs x 4 SIMDs x 16 lanes x 2 (packed): the data sheet's 78.6 T lane-ops/s is this at 2.4 GHz
+
+
 def probe_box(ctx, occupancies=(2, 8)):
-    """{waves per SIMD: T lane-ops/s} a pure v_pk_fma_f32 stream sustains on this box right now at each forced occupancy (rmgr_ssim_hip_probe_valu:
-    two untimed + five timed ~2 ms launches per occupancy, the median)."""
-    return {int(w): round(ctx.probe_valu(int(w), 0, 5), 2) for w in occupancies}
+    """{waves per SIMD: (T lane-ops/s, shader MHz)} a pure v_pk_fma_f32 stream sustains on this box right now at each forced occupancy (rmgr_ssim_hip_probe_valu:
+    40 ms of untimed launches, then five timed ~2 ms launches per occupancy, the median; the clock is what workgroup 0 of the timed launches measured)."""
+    out = {}
+    for w in occupancies:
+        t, mhz = ctx.probe_valu(int(w), 0, 5, with_clock=True)
+        out[int(w)] = (round(t, 2), round(mhz, 1))
+    return out
 
 
-def against_box(valu, mode, samples):
-    """Adds the box-relative fractions to a `valu` object: `samples` = probe_box() results taken around the timed launches (mean of them per occupancy)."""
-    if mode == 2:
+def against_box(valu, mode, samples, kernel_mhz=None):
+    """Adds the box-relative fractions to a `valu` object: `samples` = probe_box() results taken around the timed launches (mean of them per occupancy);
+    kernel_mhz = the shader clock the timed launches ran at (rmgr_ssim_hip_get_profile_clock)."""
+    if mode == 2 or not samples:
         return valu     # fp64 internals: its unit is fp64-rate issue slots, the packed-fp32 stream is not its yardstick
     waves = KERNEL_WAVES_PER_SIMD[mode]
-    mean = lambda w: sum(smp[w] for smp in samples) / len(samples)
-    at_kernel, at_8 = mean(waves), mean(8)
+    mean = lambda w, i: sum(smp[w][i] for smp in samples) / len(samples)
+    at_kernel, at_8 = mean(waves, 0), mean(8, 0)
     valu.update({"kernel_waves_per_simd": waves, "box_peak_%dwave" % waves: round(at_kernel, 2), "box_peak_8wave": round(at_8, 2),
                  "frac_of_box_peak_at_kernel_occupancy": round(valu["achieved"] / at_kernel, 4), "frac_of_box_peak": round(valu["achieved"] / at_8, 4),
-                 "box_peak_samples": [{"%dwave" % k: v for k, v in sorted(smp.items())} for smp in samples]})
+                 "box_peak_samples": [{"%dwave" % k: {"t_lane_ops_s": v[0], "shader_mhz": v[1]} for k, v in sorted(smp.items())} for smp in samples]})
+    probe_mhz = mean(waves, 1)
+    if kernel_mhz and probe_mhz:
+        # per CLOCK: what a box that merely clocks lower under this kernel's load does not change
+        k_per_clk = valu["achieved"] * 1e12 / (kernel_mhz * 1e6) / PEAK_LANE_OPS_PER_CLOCK
+        p_per_clk = at_kernel * 1e12 / (probe_mhz * 1e6) / PEAK_LANE_OPS_PER_CLOCK
+        valu.update({"shader_mhz_during_timed_launches": round(kernel_mhz, 1), "shader_mhz_during_probe": round(probe_mhz, 1),
+                     "frac_of_issue_peak_per_clock": round(k_per_clk, 4), "probe_frac_of_issue_peak_per_clock": round(p_per_clk, 4),
+                     "frac_of_box_peak_per_clock": round(k_per_clk / p_per_clk, 4)})
     return valu
 
 
@@ -393,6 +409,7 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
         box = [probe_box(ctx, occ)] if mode != 2 else []
         ctx.get_profile()
         ctx.set_profiling(True)
+        ctx.get_profile_clock()          # clears the clock counters
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.enqueue_batch(batch.params, pairs, sums.data_ptr())
@@ -400,13 +417,16 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
         wall = time.perf_counter() - t0
         ctx.set_profiling(False)
         n, ms = ctx.get_profile()
+        k_mhz, _ = ctx.get_profile_clock()
         if mode != 2:
             box.append(probe_box(ctx, occ))
     finally:
         ctx.set_mode(0)
     k_ms = ms / max(n, 1)
     roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
-    against_box(valu, mode, box)
+    against_box(valu, mode, box, k_mhz)
+    if mode == 2 and k_mhz:
+        valu["shader_mhz_during_timed_launches"] = round(k_mhz, 1)
     return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
             "kernel": kernel_name(mode, 0, want_map, plan), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
             "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
@@ -629,6 +649,13 @@ def main():
     # Every step carries a collective when there are several ranks, so the ranks must leave this loop after the SAME number of
     # steps: each looks at its own clock, and they stop when all of them have seen the quarter second (one MIN all-reduce of a flag
     # per four steps) -- a rank that stopped on its own clock one step before its peers would leave them in an all-reduce nobody answers.
+    # The box's own VALU peak (rmgr_ssim_hip_probe_valu), the yardstick the kernel's lane-operations per second are divided by: probed BEFORE the clock-settle
+    # loop and again right after the timed steps.  Not between the settle loop and the timed steps: a pure packed-FMA stream at full occupancy draws more power than
+    # the SSIM kernel, and the steps that follow it must be the kernel's own steady state, not the probe's aftermath ($SSIM_BENCH_PROBE=late puts it there for the A/B,
+    # off skips it).  Local to the rank, no collective.
+    occupancies = (2, 3, 8)
+    probe_when = os.environ.get("SSIM_BENCH_PROBE", "early")
+    box_samples = [probe_box(ctx, occupancies)] if probe_when == "early" else []
     t_settle = time.perf_counter()
     while True:
         for _ in range(4):
@@ -639,10 +666,8 @@ def main():
             settled = sharding.all_agree(dist, settled, dev)
         if settled:
             break
-    # The box's own VALU peak, right before the warm-up (clocks are settled) and again right after the timed steps: the yardstick the
-    # kernel's lane-operations per second are divided by (valu.frac_of_box_peak_at_kernel_occupancy).  Local to the rank, no collective.
-    occupancies = (2, 3, 8)
-    box_samples = [probe_box(ctx, occupancies)]
+    if probe_when == "late":
+        box_samples.append(probe_box(ctx, occupancies))
     for _ in range(args.warmup):
         step()
     fence()
@@ -650,6 +675,7 @@ def main():
     # (rmgr_ssim_hip_set_profiling): two event records per ~3 ms step, read back after the fence.
     ctx.get_profile()
     ctx.set_profiling(True)
+    ctx.get_profile_clock()              # allocates / clears the clock counters (untimed)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(timed=True)
@@ -663,7 +689,9 @@ def main():
         raise SystemExit("rank %d: the timed steps returned different sums than the gated step" % rank)
     launches, kernel_ms = ctx.get_profile()
     kernel_avg_ms = kernel_ms / max(launches, 1)
-    box_samples.append(probe_box(ctx, occupancies))
+    kernel_mhz, _ = ctx.get_profile_clock()
+    if probe_when != "off":
+        box_samples.append(probe_box(ctx, occupancies))
     if dist is not None:
         # every rank's own clock and kernel time, for the record (the number below is the MAX over ranks: one slow GPU sets it, and this says which)
         mine_ms = [None] * world
@@ -722,14 +750,17 @@ def main():
                 ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
             ctx.synchronize()
             n_f, ms_f = ctx.get_profile()
+            mhz_f, _ = ctx.get_profile_clock()
             ctx.set_profiling(False)
             ctx.set_mode(0)
             roof_f, valu_f = figures(m, mine, W, H, want_map, ms_f / n_f)
-            against_box(valu_f, m, box_samples)
+            if box_samples:
+                against_box(valu_f, m, box_samples, mhz_f)
             other[key] = {"mode": MODE_NAMES[m], "kernel": kernel_name(m, args.variant, want_map, plan_m),
                           "kernel_avg_ms": round(ms_f / n_f, 4), "mpix_s": round(float(mine) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1),
                           "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"], "ops_per_pixel": valu_f["ops_per_pixel"],
-                          "valu_frac_of_box_peak_at_kernel_occupancy": valu_f["frac_of_box_peak_at_kernel_occupancy"], "kernel_waves_per_simd": valu_f["kernel_waves_per_simd"]}
+                          "valu_frac_of_box_peak_at_kernel_occupancy": valu_f.get("frac_of_box_peak_at_kernel_occupancy"), "kernel_waves_per_simd": valu_f.get("kernel_waves_per_simd"),
+                          "shader_mhz": valu_f.get("shader_mhz_during_timed_launches"), "valu_frac_of_box_peak_per_clock": valu_f.get("frac_of_box_peak_per_clock")}
         ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
         ctx.synchronize()
 
@@ -884,11 +915,15 @@ def main():
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
                          "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
-            against_box(valu, args.mode, box_samples)
-            valu.update({"box_peak_2wave": round(sum(b[2] for b in box_samples) / len(box_samples), 2),
+            if box_samples:
+                against_box(valu, args.mode, box_samples, kernel_mhz)
+            valu.update({"box_peak_2wave": round(sum(b[2][0] for b in box_samples) / len(box_samples), 2) if box_samples else None,
                          "box_peak_note": "rmgr_ssim_hip_probe_valu in this process, on this box: a pure v_pk_fma_f32 stream at a FORCED occupancy of 2 / 8 waves per SIMD "
-                                          "(register footprint padded, grid = the chip's capacity), median of 5 launches of ~2 ms each, once right before the warm-up "
-                                          "steps and once right after the timed steps (box_peak_samples, in that order); the fractions divide by the mean of the two",
+                                          "(register footprint padded, grid = the chip's capacity; 40 ms of untimed launches, then the median of 5 launches of ~2 ms each), once before the "
+                                          "clock-settle loop that precedes the warm-up steps and once right after the timed steps (box_peak_samples, in that order); the fractions divide by the mean of the two; "
+                                          "shader_mhz_*: the clock workgroup 0 of the timed strip-kernel launches / of the probe's timed launches really ran at (s_memtime cycles per s_memrealtime tick, "
+                                          "rmgr_ssim_hip_get_profile_clock); frac_of_issue_peak_per_clock = lane-operations per shader cycle over the 32768 the chip can issue; "
+                                          "frac_of_box_peak_per_clock = that figure over the probe's: what a box that only clocks lower under this kernel's load leaves unchanged",
                          "round4_box_constants": dict(ROUND4_BOX_VALU_TOPS, note="what rounds 4-5 divided by (one round-4 box, tools/occupancy_probe.hip); for comparison only")})
         line = {
             "metric": "Mpix/s (global SSIM, no map) on 4K pairs; achieved HBM GB/s vs roofline",

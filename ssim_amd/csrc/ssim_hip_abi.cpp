@@ -71,6 +71,8 @@ struct rmgr_ssim_hip_Context_ {
     hipEvent_t map_ev[2];
 
     bool profiling;
+    uint64_t* clock_dev;      // 5 device counters the profiled strip launches' workgroup 0 adds its shader cycles / 100 MHz ticks to (ssim_kernels.hip clock_begin); NULL until profiling is first enabled
+    int       wall_clock_khz; // rate of s_memrealtime (hipDeviceAttributeWallClockRate; 100 MHz on MI355X)
     std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;   // recorded, not yet read
     std::vector<std::pair<hipEvent_t, hipEvent_t> > free_events;
     uint64_t prof_launches;
@@ -295,7 +297,7 @@ int enqueue(rmgr_ssim_hip_Context* c, uint32_t width, uint32_t height, uint32_t 
     const bool launches_kernel = count > 0 && geo.strips_x > 0 && geo.strips_y > 0;
     hipEvent_t eb = NULL, ee = NULL;
     if (launches_kernel && (rc = acquire_events(c, eb, ee))) return rc;
-    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, cells_out ? cells_out : c->partials, sums_dev, c->stream, eb, ee, reduce);
+    const hipError_t err = ssim_hip::launch(geo, c->mode, variant, ssim_hip::interleaved_group(descs, count), descs_dev, single, cells_out ? cells_out : c->partials, sums_dev, c->stream, eb, ee, reduce, c->profiling ? c->clock_dev : NULL);
     if (err != hipSuccess) {
         (void)hipGetLastError();
         release_events(c, eb, ee);
@@ -881,6 +883,13 @@ rmgr_int32_t rmgr_ssim_hip_create(rmgr_ssim_hip_Context** out, rmgr_int32_t devi
     c->comm_nonblocking = false;
     c->comm_ranks = 0;
     c->profiling = false;
+    c->clock_dev = NULL;
+    c->wall_clock_khz = 100000;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) c->wall_clock_khz = khz;
+        else (void)hipGetLastError();
+    }
     c->prof_launches = 0;
     c->prof_ms = 0.0;
     if (!stream) {
@@ -906,6 +915,7 @@ rmgr_int32_t rmgr_ssim_hip_destroy(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     for (size_t i = 0; i < c->pending.size(); ++i) { (void)hipEventDestroy(c->pending[i].first); (void)hipEventDestroy(c->pending[i].second); }
     for (size_t i = 0; i < c->free_events.size(); ++i) { (void)hipEventDestroy(c->free_events[i].first); (void)hipEventDestroy(c->free_events[i].second); }
     if (c->partials) (void)hipFree(c->partials);
+    if (c->clock_dev) (void)hipFree(c->clock_dev);
     for (int i = 0; i < rmgr_ssim_hip_Context_::kDescSlots; ++i) {
         if (c->desc_slots[i].dev) (void)hipFree(c->desc_slots[i].dev);
         if (c->desc_slots[i].host) (void)hipHostFree(c->desc_slots[i].host);
@@ -2048,11 +2058,40 @@ rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* c, void* dst, const
     return 0;
 }
 
+namespace {
+// Reads and clears the clock counters the profiled launches added to (after the stream is idle): *mhz = the shader clock workgroup 0 of those launches ran at.
+int read_clock(rmgr_ssim_hip_Context* c, double* mhz, rmgr_uint64_t* launches)
+{
+    if (mhz) *mhz = 0.0;
+    if (launches) *launches = 0;
+    if (!c->clock_dev) return 0;
+    uint64_t v[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(v, c->clock_dev, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemsetAsync(c->clock_dev, 0, sizeof(v), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (v[3] != 0 && mhz) *mhz = (double)v[2] / (double)v[3] * (double)c->wall_clock_khz / 1000.0;
+    if (launches) *launches = v[4];
+    return 0;
+}
+} // namespace
+
 rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* c, rmgr_int32_t enabled) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
+    if (enabled && !c->clock_dev) {
+        USE_DEVICE(c);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->clock_dev), 5 * sizeof(uint64_t)));
+        HIP_TRY(hipMemsetAsync(c->clock_dev, 0, 5 * sizeof(uint64_t), c->stream));
+    }
     c->profiling = enabled != 0;
     return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_profile_clock(rmgr_ssim_hip_Context* c, double* shaderMHz, rmgr_uint64_t* launches) RMGR_NOEXCEPT
+{
+    if (!c) return EINVAL;
+    USE_DEVICE(c);
+    return read_clock(c, shaderMHz, launches);
 }
 
 rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* c, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT
@@ -2221,7 +2260,7 @@ rmgr_int32_t rmgr_ssim_hip_clear_tuned(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
     return 0;
 }
 
-rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* c, rmgr_int32_t wavesPerSimd, rmgr_int32_t streamKind, rmgr_int32_t launches, double* teraLaneOps) RMGR_NOEXCEPT
+rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* c, rmgr_int32_t wavesPerSimd, rmgr_int32_t streamKind, rmgr_int32_t launches, double* teraLaneOps, double* shaderMHz) RMGR_NOEXCEPT
 {
     if (!c || !teraLaneOps || launches < 1 || launches > 64 || (streamKind != 0 && streamKind != 1)) return EINVAL;
     if (wavesPerSimd != 1 && wavesPerSimd != 2 && wavesPerSimd != 3 && wavesPerSimd != 4 && wavesPerSimd != 8) return EINVAL;
@@ -2231,14 +2270,24 @@ rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* c, rmgr_int32_t wav
     const int iters = 40000 / wavesPerSimd;
     int rc = grow_device(c->partials, c->partials_cap, 64);        // the kernel's (never written) output pointer
     if (rc) return rc;
+    uint64_t* clock = NULL;                                        // the timed launches' workgroup 0 reports the shader clock it ran at (doubles 32 ... 36 of the scratch)
+    if (shaderMHz) {
+        clock = reinterpret_cast<uint64_t*>(c->partials + 32);
+        HIP_TRY(hipMemsetAsync(clock, 0, 5 * sizeof(uint64_t), c->stream));
+    }
     hipEvent_t eb = NULL, ee = NULL;
     HIP_TRY(hipEventCreate(&eb));
     hipError_t err = hipEventCreate(&ee);
     if (err != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(eb); return map_hip_error(err); }
     float ms[64];
+    // the chip takes ~25 ms of sustained load to leave its idle clock: untimed launches for 40 ms of wall time first (a probe of an idle device read 12 % low)
+    for (const Clock::time_point t0 = Clock::now(); err == hipSuccess && std::chrono::duration<double>(Clock::now() - t0).count() < 0.040; ) {
+        err = ssim_hip::launch_probe_valu(wavesPerSimd, streamKind, c->cu_count, iters, reinterpret_cast<float*>(c->partials), c->stream);
+        if (err == hipSuccess) err = hipStreamSynchronize(c->stream);
+    }
     for (int k = -2; k < launches && err == hipSuccess; ++k) {
         if (k >= 0) err = hipEventRecord(eb, c->stream);
-        if (err == hipSuccess) err = ssim_hip::launch_probe_valu(wavesPerSimd, streamKind, c->cu_count, iters, reinterpret_cast<float*>(c->partials), c->stream);
+        if (err == hipSuccess) err = ssim_hip::launch_probe_valu(wavesPerSimd, streamKind, c->cu_count, iters, reinterpret_cast<float*>(c->partials), c->stream, k >= 0 ? clock : NULL);
         if (k >= 0 && err == hipSuccess) err = hipEventRecord(ee, c->stream);
         if (k >= 0 && err == hipSuccess) err = hipEventSynchronize(ee);
         if (k >= 0 && err == hipSuccess) err = hipEventElapsedTime(&ms[k], eb, ee);
@@ -2250,6 +2299,11 @@ rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* c, rmgr_int32_t wav
     const float med = ms[launches / 2];
     if (!(med > 0.f)) return ECHILD;
     *teraLaneOps = (double)ssim_hip::probe_valu_lane_ops(wavesPerSimd, c->cu_count, iters) / ((double)med * 1e-3) / 1e12;
+    if (shaderMHz) {
+        uint64_t v[5] = {0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(v, clock, sizeof(v), hipMemcpyDeviceToHost));
+        *shaderMHz = v[3] ? (double)v[2] / (double)v[3] * (double)c->wall_clock_khz / 1000.0 : 0.0;
+    }
     return 0;
 }
 

@@ -128,8 +128,9 @@ size_t partials_size(const Geometry& geo);
 //   group       > 1 when every run of `group` consecutive descriptors addresses the interleaved channels of one
 //               image pair (interleaved_group()): scheduling hint only, results do not depend on it
 // ev_begin/ev_end (optional) are recorded around the main kernel only.
+// clock (optional, profiling): 5 device uint64; workgroup 0 of the strip kernel adds its shader cycles to clock[2], its 100 MHz reference ticks to clock[3], 1 to clock[4].
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true);
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true, uint64_t* clock = nullptr);
 
 // The reduction alone: per-image sums of `geo.count` images' cell partials (partials: [image][cell_y][cell_x], the layout
 // launch() writes), in the fixed order every launch uses.  chunk_sums: reduce_scratch_size(geo) doubles of device scratch
@@ -153,7 +154,7 @@ hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b
 // Profiling aid (ssim_probe.hip): a pure packed-fp32 stream at a FORCED occupancy of waves_per_simd (1, 2, 3, 4 or 8) waves per SIMD on
 // a grid of exactly cu_count x 4 x waves_per_simd single-wave workgroups; stream_kind 0: independent v_pk_fma_f32, 1: two interleaved
 // dependent chains of six (the shape of the blur's row sums).  probe_valu_lane_ops(): the lane-operations one such launch retires.
-hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream);
+hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream, uint64_t* clock = nullptr);   // clock: as launch()'s
 uint64_t probe_valu_lane_ops(int waves_per_simd, int cu_count, int iters);
 
 } // namespace ssim_hip

@@ -409,6 +409,8 @@ struct KArgs {
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
+    uint64_t*       clock;        // profiling only (NULL otherwise): workgroup 0 adds the shader cycles (s_memtime) and the 100 MHz reference ticks (s_memrealtime) of its
+                                  // own run to clock[2], clock[3] and 1 to clock[4] -- the shader clock the kernel really ran at (clock_begin / clock_end)
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
     double          c1d, c2d;
@@ -430,6 +432,25 @@ struct Strip {
     int64_t  W, H, x0, y0, y_end;
     uint32_t sx, sy, img;
 };
+
+// Profiling aid (rmgr_ssim_hip_set_profiling): the shader clock a launch really ran at.  Workgroup 0 notes s_memtime (one tick per shader cycle) and s_memrealtime
+// (100 MHz) when it starts and adds the differences to two device counters when it ends: frequency = 100 MHz x cycles / ticks, averaged over the profiled launches.
+// Nothing is held in registers in between (the start values wait in memory), and with clock == NULL it is one scalar branch at either end of the kernel.
+__device__ __forceinline__ void clock_begin(uint64_t* clock)
+{
+    const uint64_t t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { clock[0] = t; clock[1] = r; }
+}
+__device__ __forceinline__ void clock_end(uint64_t* clock)
+{
+    const uint64_t t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 2), (unsigned long long)(t - clock[0]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 3), (unsigned long long)(r - clock[1]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 4), 1ull);
+    }
+}
+#define SSIM_CLOCKED(args) ((args).clock != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
 
 // Workgroup g of `total` -> its place in the work list when each of the `xcds` XCDs (which the dispatcher deals consecutive
 // workgroup ids to, round robin) is to walk ONE contiguous share of the list: XCD k owns total / xcds entries, the first
@@ -708,6 +729,7 @@ void ssim_strip2_kernel(const KArgs args)
     // the separable taps as six scalars (an array inside the kernel argument block, passed on by reference, can end up
     // in scratch memory when scalar and packed streams both use it)
     const float gf[6] = {args.gf[0], args.gf[1], args.gf[2], args.gf[3], args.gf[4], args.gf[5]};
+    if (SSIM_CLOCKED(args)) clock_begin(args.clock);
     Work wk = {0, 0};
     if constexpr (BAL) wk = work_setup(args);
 #pragma unroll 1
@@ -1052,6 +1074,7 @@ void ssim_strip2_kernel(const KArgs args)
     }
     if constexpr (BAL) wave_sync();     // the next segment re-uses the LDS slots and the cell batch
     } while (BAL && wk.end > wk.first);
+    if (SSIM_CLOCKED(args)) clock_end(args.clock);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1097,6 +1120,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
     __shared__ __attribute__((aligned(16))) CellBatch cells;
 
     const int lane = threadIdx.x;
+    if (SSIM_CLOCKED(args)) clock_begin(args.clock);
     const Strip st = strip_setup(args, Slot1::STRIP_W);
     const PairDesc& pd = st.pd;
     typedef typename std::conditional<WIDE, int64_t, int>::type idx_t;       // coordinates
@@ -1314,6 +1338,7 @@ __global__ __launch_bounds__(64) void ssim_strip1_kernel(const KArgs args)
         wave_sync();
         cell_batch_flush1(args, st, cells, cell_y, parked);
     }
+    if (SSIM_CLOCKED(args)) clock_end(args.clock);
 }
 
 // Per-image sum of the cell partials in a fixed order, so that the result depends on nothing but the image size:
@@ -1679,7 +1704,7 @@ hipError_t launch_reduce(const Geometry& geo, const double* partials, double* ch
 }
 
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
-                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce)
+                  double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce, uint64_t* clock)
 {
     if (geo.count == 0) return hipSuccess;
     KArgs ka;
@@ -1698,6 +1723,7 @@ hipError_t launch(const Geometry& geo, int mode, int variant, int group, const P
     ka.count = geo.count;
     ka.group = (group > 1 && geo.count % (uint32_t)group == 0) ? (uint32_t)group : 1u;
     ka.partials = partials;
+    ka.clock = clock;
     // c1, c2: products in double, then cast (src/ssim.cpp:956-960)
     ka.c1d = (0.01 * 255.0) * (0.01 * 255.0);
     ka.c2d = (0.03 * 255.0) * (0.03 * 255.0);

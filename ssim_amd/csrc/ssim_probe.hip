@@ -5,8 +5,9 @@
 // packed fp32 instructions at the occupancy the kernel's registers allow -- two waves per SIMD for the bit-exact kernels (110 accumulator
 // VGPRs), three for MODE_SEPARABLE / MODE_DOUBLE.  Rounds 4-5 took that rate from one run of tools/occupancy_probe.hip on one box (65.1 / 74.6 T
 // lane-ops/s at 2 / 8 waves) and divided every later kernel time, measured on other boxes, by it; the boxes of the pool differ by +-4 %
-// (profiles/r05_box_spread.md), more than any kernel change of rounds 4-5 was worth.  bench.py now runs this probe in-process right before
-// the warm-up and right after the timed steps and reports the kernel against the SAME box's peak in the SAME run.
+// (profiles/r05_box_spread.md), more than any kernel change of rounds 4-5 was worth.  bench.py now runs this probe in-process before the
+// clock-settle loop and right after the timed steps and reports the kernel against the SAME box's peak in the SAME run -- together with the shader
+// clock both really ran at (workgroup 0 reads s_memtime / s_memrealtime), because boxes also differ in the clock they hold under the SSIM kernel's load.
 //
 // How the occupancy is forced: the kernel's register footprint is padded (a clobbered high register raises the VGPR count in the kernel
 // descriptor) so that the hardware cannot place more than W waves on a SIMD, and the grid is exactly the chip's capacity at that occupancy
@@ -35,9 +36,14 @@ template <int W> __device__ __forceinline__ void pad_registers()
 enum { PROBE_ACCS = 24 };
 
 template <int W, int STREAM>
-__global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, float seed)
+__global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, float seed, uint64_t* clock)
 {
     pad_registers<W>();
+    // the shader clock this launch runs at, as the strip kernels report theirs (ssim_kernels.hip clock_begin / clock_end): workgroup 0 adds its cycles and
+    // its 100 MHz reference ticks to two counters
+    uint64_t cycles0 = 0, ticks0 = 0;
+    const bool clocked = clock != nullptr && blockIdx.x == 0;
+    if (clocked) { cycles0 = __builtin_readcyclecounter(); ticks0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int N = PROBE_ACCS;
     f2 acc[N];
 #pragma unroll
@@ -67,13 +73,18 @@ __global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, f
 #pragma unroll
     for (int j = 0; j < N; ++j) s += acc[j];
     if (s.x == 12345.678f) out[threadIdx.x] = s.x + s.y;      // never true: keeps the accumulators alive
+    if (clocked && threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 2), (unsigned long long)(__builtin_readcyclecounter() - cycles0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 3), (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ticks0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 4), 1ull);
+    }
 }
 
 template <int W>
-hipError_t launch_w(int stream_kind, int blocks, float* out, int iters, hipStream_t stream)
+hipError_t launch_w(int stream_kind, int blocks, float* out, int iters, hipStream_t stream, uint64_t* clock)
 {
-    if (stream_kind == 0) hipLaunchKernelGGL((probe_valu_kernel<W, 0>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f);
-    else                  hipLaunchKernelGGL((probe_valu_kernel<W, 1>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f);
+    if (stream_kind == 0) hipLaunchKernelGGL((probe_valu_kernel<W, 0>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock);
+    else                  hipLaunchKernelGGL((probe_valu_kernel<W, 1>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock);
     return hipGetLastError();
 }
 
@@ -85,15 +96,15 @@ uint64_t probe_valu_lane_ops(int waves_per_simd, int cu_count, int iters)
     return (uint64_t)128 * PROBE_ACCS * (uint64_t)iters * (uint64_t)cu_count * 4u * (uint64_t)waves_per_simd;
 }
 
-hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream)
+hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream, uint64_t* clock)
 {
     const int blocks = cu_count * 4 * waves_per_simd;
     switch (waves_per_simd) {
-    case 1: return launch_w<1>(stream_kind, blocks, out, iters, stream);
-    case 2: return launch_w<2>(stream_kind, blocks, out, iters, stream);
-    case 3: return launch_w<3>(stream_kind, blocks, out, iters, stream);
-    case 4: return launch_w<4>(stream_kind, blocks, out, iters, stream);
-    case 8: return launch_w<8>(stream_kind, blocks, out, iters, stream);
+    case 1: return launch_w<1>(stream_kind, blocks, out, iters, stream, clock);
+    case 2: return launch_w<2>(stream_kind, blocks, out, iters, stream, clock);
+    case 3: return launch_w<3>(stream_kind, blocks, out, iters, stream, clock);
+    case 4: return launch_w<4>(stream_kind, blocks, out, iters, stream, clock);
+    case 8: return launch_w<8>(stream_kind, blocks, out, iters, stream, clock);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1,4 +1,4 @@
-"""CPU: the measured table in DESIGN.md is the one tools/design_table.py generates from the committed bench line (profiles/r05_final_bench.json, the rocprofv3 trace
+"""CPU: the measured table in DESIGN.md is the one tools/design_table.py generates from the committed bench line (profiles/r06_final_bench.json, the rocprofv3 trace
 summary, profiles/traffic.json) -- a number quoted in the design document that no committed measurement backs would fail here --, and the trace summariser keeps launches of
 different workloads apart even when they share a kernel and a grid (the balanced form is launched with one wavefront per wave slot whatever the batch)."""
 import os
@@ -10,7 +10,7 @@ from conftest import ROOT
 
 def test_design_table_matches_the_committed_bench_line():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_table.py"), "--check"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, "DESIGN.md's Measured (round 5) table differs from what tools/design_table.py generates from profiles/: run it\n" + r.stdout + r.stderr
+    assert r.returncode == 0, "DESIGN.md's Measured (round 6) table differs from what tools/design_table.py generates from profiles/: run it\n" + r.stdout + r.stderr
 
 
 def test_trace_summary_splits_one_grid_by_duration(tmp_path):

@@ -22,7 +22,7 @@ for case in range(CASES):
     b=np.clip(a.astype(np.int32)+rng.integers(-40,41,(h,w)),0,255).astype(np.uint8)
     mode=int(rng.choice([0,0,0,3,1,1,4,4,2]))
     ba,oa,sa,da_=make_layout(rng,a); bb,ob,sb,db_=make_layout(rng,b)
-    variant=int(rng.choice([0,0,1,2,3,6])); rows=int(rng.choice([0,0,0,2,9,31,64,300]))
+    variant=int(rng.choice([0,0,1,2,3,6,7,103])); rows=int(rng.choice([0,0,0,2,9,31,64,300]))
     nomap = case % 4 == 3          # every fourth case asks for the global value only: the launches without a map are the ones plan() may give the balanced form
     keep=[]
     try:

@@ -11,14 +11,14 @@ pmc() {   # name, counters, target args...
   local name=$1 ctrs=$2; shift 2
   timeout 300 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d "$OUT/$name" -o t -- python3 tools/profile_target.py "$@" > "$OUT/$name.log" 2>&1
 }
-for cfg in "4k 32 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
+for cfg in "4k 32 3 0 0 4096 4096" "8kmap 2 3 0 1 8192 8192" "1080p 128 3 0 0 1920 1080" "1080p32 32 3 0 0 1920 1080" "4kfast 8 3 1 0 4096 4096" "4ksep 8 3 4 0 4096 4096" "4kdouble 4 3 2 1 4096 4096"; do
   set -- $cfg; tag=$1; shift
   pmc ${tag}_fetch FETCH_SIZE "$@"
   pmc ${tag}_write WRITE_SIZE "$@"
   pmc ${tag}_sq  "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "$@"
   pmc ${tag}_sq2 "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY" "$@"
 done
-python3 tools/make_traffic_json.py "$OUT" r05 profiles/traffic.json > "$OUT/traffic_ratios.json" && cp profiles/traffic.json "$OUT/traffic.json"
+python3 tools/make_traffic_json.py "$OUT" r06 profiles/traffic.json > "$OUT/traffic_ratios.json" && cp profiles/traffic.json "$OUT/traffic.json"
 for wl in 4k 8k-map 1080p; do
   timeout 600 python3 bench.py --workload $wl > "$OUT/bench_$wl.log" 2>&1
   grep '"metric"' "$OUT/bench_$wl.log" > "$OUT/bench_$wl.json"
@@ -47,7 +47,8 @@ timeout 900 python3 tests/tools/error_table.py > "$OUT/error_table.md" 2> "$OUT/
 # round 5: what a first call costs, what concurrent callers get, and the long parity runs of the final kernels
 { for w in plain split cli plain split; do timeout 120 python3 tools/cold_start_probe.py $w; done; } > "$OUT/cold_start.txt" 2>&1
 { for cfg in "4096 1" "4096 0" "1920 1"; do echo "# size map: $cfg"; timeout 120 python3 tools/concurrent_callers.py $cfg 1,2,4,6 1.5; done; echo "# RMGR_SSIM_HIP_POOL=1"; RMGR_SSIM_HIP_POOL=1 timeout 120 python3 tools/concurrent_callers.py 4096 1 1,4 1.5; } > "$OUT/concurrent_callers.txt" 2>&1
-{ time timeout 900 python3 tests/tools/soak.py 30000 20261003; } > "$OUT/soak.txt" 2>&1
+timeout 600 python3 tools/tune_sweep.py 0 0 quick > "$OUT/tune_sweep_quick.txt" 2>&1
+{ time timeout 900 python3 tests/tools/soak.py 30000 20261004; } > "$OUT/soak.txt" 2>&1
 timeout 900 python3 tests/tools/fullsize_check.py > "$OUT/fullsize_check.txt" 2>&1
 timeout 300 python3 tools/balanced_check.py > "$OUT/balanced_check.txt" 2>&1
 find "$OUT" -name "*.csv" | wc -l

@@ -31,8 +31,10 @@ def entry(tag, pairs, alg):
 t = {"kernel_source_sha256": hashlib.sha256(open(os.path.join(ROOT, "ssim_amd", "csrc", "ssim_kernels.hip"), "rb").read()).hexdigest(),
      "_comment": "kernel_source_sha256 = the ssim_kernels.hip these passes ran (bench.py quotes the figures for that version only: rmgr_ssim_hip_get_kernel_source_id). "
                  "HBM bytes per launch measured with rocprofv3 --pmc (separate passes for FETCH_SIZE and WRITE_SIZE; FETCH_SIZE doubled per profiles/r01_fetch_size_calibration.md), "
-                 "expressed per image pair; the 4096^2 entry is the headline batch itself (32 pairs: nothing scaled). Sources: profiles/%s_final_exact_4k_pmc.md, "
+                 "expressed per image pair; the 4096^2 entry is the headline batch itself (32 pairs) and the 1080p entry configs[3]'s per-GPU share itself (128 pairs): nothing scaled (round 5 measured 32 pairs and scaled -- a different plan); exact_1080p_32pairs_nomap: 32 pairs, for the record. Sources: profiles/%s_final_exact_4k_pmc.md, "
                  "%s_final_exact_8k_map_pmc.md, %s_final_exact_1080p_pmc.md" % (R, R, R),
-     "exact_4096_nomap": entry("4k", 32, 2 * 4096 * 4096), "exact_8192_map": entry("8kmap", 2, 6 * 8192 * 8192), "exact_1080p_nomap": entry("1080p", 32, 2 * 1920 * 1080)}
+     "exact_4096_nomap": entry("4k", 32, 2 * 4096 * 4096), "exact_8192_map": entry("8kmap", 2, 6 * 8192 * 8192), "exact_1080p_nomap": entry("1080p", 128, 2 * 1920 * 1080)}
+if os.path.isdir("%s/1080p32_fetch" % P):
+    t["exact_1080p_32pairs_nomap"] = entry("1080p32", 32, 2 * 1920 * 1080)
 json.dump(t, open(OUT, "w"), indent=1)
 print(json.dumps({k: v["ratio"] for k, v in t.items() if isinstance(v, dict)}))
