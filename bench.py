@@ -334,31 +334,34 @@ PEAK_LANE_OPS_PER_CLOCK = 32768.0      # 256 CUs x 4 SIMDs x 16 lanes x 2 (packe
 
 def probe_box(ctx, occupancies=(2, 8)):
     """{waves per SIMD: (T lane-ops/s, shader MHz)} a pure v_pk_fma_f32 stream sustains on this box right now at each forced occupancy (rmgr_ssim_hip_probe_valu:
-    40 ms of untimed launches, then five timed ~2 ms launches per occupancy, the median; the clock is what workgroup 0 of the timed launches measured)."""
+    three bursts of untimed + five timed ~2 ms launches per occupancy, the best burst's median; the clocks are what one workgroup per XCD of that burst measured)."""
     out = {}
     for w in occupancies:
-        t, mhz = ctx.probe_valu(int(w), 0, 5, with_clock=True)
-        out[int(w)] = (round(t, 2), round(mhz, 1))
+        t, mhz, lo = ctx.probe_valu(int(w), 0, 5, with_clock=True)
+        out[int(w)] = (round(t, 2), round(mhz, 1), round(lo, 1))
     return out
 
 
-def against_box(valu, mode, samples, kernel_mhz=None):
+def against_box(valu, mode, samples, kernel_clock=None):
     """Adds the box-relative fractions to a `valu` object: `samples` = probe_box() results taken around the timed launches (mean of them per occupancy);
-    kernel_mhz = the shader clock the timed launches ran at (rmgr_ssim_hip_get_profile_clock)."""
+    kernel_clock = (mean, slowest XCD's) shader MHz the timed launches ran at (rmgr_ssim_hip_get_profile_clock)."""
     if mode == 2 or not samples:
         return valu     # fp64 internals: its unit is fp64-rate issue slots, the packed-fp32 stream is not its yardstick
     waves = KERNEL_WAVES_PER_SIMD[mode]
-    mean = lambda w, i: sum(smp[w][i] for smp in samples) / len(samples)
-    at_kernel, at_8 = mean(waves, 0), mean(8, 0)
+    best = lambda w: max(samples, key=lambda smp: smp[w][0])[w]        # the peak is the best sample: a probe burst can run degraded (rmgr/ssim-hip.h), never enhanced
+    mean = lambda w, i: best(w)[i]
+    at_kernel, at_8 = best(waves)[0], best(8)[0]
     valu.update({"kernel_waves_per_simd": waves, "box_peak_%dwave" % waves: round(at_kernel, 2), "box_peak_8wave": round(at_8, 2),
                  "frac_of_box_peak_at_kernel_occupancy": round(valu["achieved"] / at_kernel, 4), "frac_of_box_peak": round(valu["achieved"] / at_8, 4),
-                 "box_peak_samples": [{"%dwave" % k: {"t_lane_ops_s": v[0], "shader_mhz": v[1]} for k, v in sorted(smp.items())} for smp in samples]})
+                 "box_peak_samples": [{"%dwave" % k: {"t_lane_ops_s": v[0], "shader_mhz": v[1], "slowest_xcd_mhz": v[2]} for k, v in sorted(smp.items())} for smp in samples]})
     probe_mhz = mean(waves, 1)
+    kernel_mhz = kernel_clock[0] if kernel_clock else None
     if kernel_mhz and probe_mhz:
         # per CLOCK: what a box that merely clocks lower under this kernel's load does not change
         k_per_clk = valu["achieved"] * 1e12 / (kernel_mhz * 1e6) / PEAK_LANE_OPS_PER_CLOCK
         p_per_clk = at_kernel * 1e12 / (probe_mhz * 1e6) / PEAK_LANE_OPS_PER_CLOCK
-        valu.update({"shader_mhz_during_timed_launches": round(kernel_mhz, 1), "shader_mhz_during_probe": round(probe_mhz, 1),
+        valu.update({"shader_mhz_during_timed_launches": round(kernel_mhz, 1), "slowest_xcd_mhz_during_timed_launches": round(kernel_clock[1], 1),
+                     "shader_mhz_during_probe": round(probe_mhz, 1), "slowest_xcd_mhz_during_probe": round(mean(waves, 2), 1),
                      "frac_of_issue_peak_per_clock": round(k_per_clk, 4), "probe_frac_of_issue_peak_per_clock": round(p_per_clk, 4),
                      "frac_of_box_peak_per_clock": round(k_per_clk / p_per_clk, 4)})
     return valu
@@ -417,16 +420,16 @@ def time_config(torch, np, ssim_amd, synth, ctx, dev, name, w, h, pairs, want_ma
         wall = time.perf_counter() - t0
         ctx.set_profiling(False)
         n, ms = ctx.get_profile()
-        k_mhz, _ = ctx.get_profile_clock()
+        k_clock = ctx.get_profile_clock()[:2]
         if mode != 2:
             box.append(probe_box(ctx, occ))
     finally:
         ctx.set_mode(0)
     k_ms = ms / max(n, 1)
     roof, valu = figures(mode, pairs, w, h, want_map, k_ms)
-    against_box(valu, mode, box, k_mhz)
-    if mode == 2 and k_mhz:
-        valu["shader_mhz_during_timed_launches"] = round(k_mhz, 1)
+    against_box(valu, mode, box, k_clock)
+    if mode == 2 and k_clock[0]:
+        valu["shader_mhz_during_timed_launches"], valu["slowest_xcd_mhz_during_timed_launches"] = round(k_clock[0], 1), round(k_clock[1], 1)
     return {"workload": "%d x %dx%d%s" % (pairs, w, h, " + map" if want_map else ""), "mode": MODE_NAMES[mode], "gate": gate,
             "kernel": kernel_name(mode, 0, want_map, plan), "kernel_avg_ms": round(k_ms, 4), "launches_timed": int(n),
             "mpix_s": round(float(pairs) * w * h / (k_ms * 1e-3) / 1e6, 1),
@@ -689,7 +692,7 @@ def main():
         raise SystemExit("rank %d: the timed steps returned different sums than the gated step" % rank)
     launches, kernel_ms = ctx.get_profile()
     kernel_avg_ms = kernel_ms / max(launches, 1)
-    kernel_mhz, _ = ctx.get_profile_clock()
+    kernel_clock = ctx.get_profile_clock()[:2]
     if probe_when != "off":
         box_samples.append(probe_box(ctx, occupancies))
     if dist is not None:
@@ -750,12 +753,12 @@ def main():
                 ctx.enqueue_batch(batch.params, mine, my_slice_ptr)
             ctx.synchronize()
             n_f, ms_f = ctx.get_profile()
-            mhz_f, _ = ctx.get_profile_clock()
+            clock_f = ctx.get_profile_clock()[:2]
             ctx.set_profiling(False)
             ctx.set_mode(0)
             roof_f, valu_f = figures(m, mine, W, H, want_map, ms_f / n_f)
             if box_samples:
-                against_box(valu_f, m, box_samples, mhz_f)
+                against_box(valu_f, m, box_samples, clock_f)
             other[key] = {"mode": MODE_NAMES[m], "kernel": kernel_name(m, args.variant, want_map, plan_m),
                           "kernel_avg_ms": round(ms_f / n_f, 4), "mpix_s": round(float(mine) * W * H / (ms_f / n_f * 1e-3) / 1e6, 1),
                           "roofline_frac": roof_f["frac"], "valu_frac": valu_f["frac"], "ops_per_pixel": valu_f["ops_per_pixel"],
@@ -916,13 +919,13 @@ def main():
                          "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
                          "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
             if box_samples:
-                against_box(valu, args.mode, box_samples, kernel_mhz)
-            valu.update({"box_peak_2wave": round(sum(b[2][0] for b in box_samples) / len(box_samples), 2) if box_samples else None,
+                against_box(valu, args.mode, box_samples, kernel_clock)
+            valu.update({"box_peak_2wave": max(b[2][0] for b in box_samples) if box_samples else None,
                          "box_peak_note": "rmgr_ssim_hip_probe_valu in this process, on this box: a pure v_pk_fma_f32 stream at a FORCED occupancy of 2 / 8 waves per SIMD "
                                           "(register footprint padded, grid = the chip's capacity; 40 ms of untimed launches, then the median of 5 launches of ~2 ms each), once before the "
-                                          "clock-settle loop that precedes the warm-up steps and once right after the timed steps (box_peak_samples, in that order); the fractions divide by the mean of the two; "
-                                          "shader_mhz_*: the clock workgroup 0 of the timed strip-kernel launches / of the probe's timed launches really ran at (s_memtime cycles per s_memrealtime tick, "
-                                          "rmgr_ssim_hip_get_profile_clock); frac_of_issue_peak_per_clock = lane-operations per shader cycle over the 32768 the chip can issue; "
+                                          "clock-settle loop that precedes the warm-up steps and once right after the timed steps (box_peak_samples, in that order); the fractions divide by the BETTER of the two (a probe burst can run in a degraded mode, never in an enhanced one: rmgr/ssim-hip.h); "
+                                          "shader_mhz_* / slowest_xcd_mhz_*: the clock the timed strip-kernel launches / the probe's timed launches really ran at, mean over the XCDs and the slowest XCD's "
+                                          "(one workgroup per XCD counts s_memtime cycles per s_memrealtime tick: rmgr_ssim_hip_get_profile_clock); frac_of_issue_peak_per_clock = lane-operations per shader cycle over the 32768 the chip can issue; "
                                           "frac_of_box_peak_per_clock = that figure over the probe's: what a box that only clocks lower under this kernel's load leaves unchanged",
                          "round4_box_constants": dict(ROUND4_BOX_VALU_TOPS, note="what rounds 4-5 divided by (one round-4 box, tools/occupancy_probe.hip); for comparison only")})
         line = {

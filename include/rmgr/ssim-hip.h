@@ -352,27 +352,30 @@ rmgr_int32_t rmgr_ssim_hip_memcpy_d2h(rmgr_ssim_hip_Context* ctx, void* hostPtr,
  */
 rmgr_int32_t rmgr_ssim_hip_set_profiling(rmgr_ssim_hip_Context* ctx, rmgr_int32_t enabled) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_get_profile(rmgr_ssim_hip_Context* ctx, rmgr_uint64_t* launches, double* kernelMs) RMGR_NOEXCEPT;
-/* The shader clock the profiled launches really ran at (round 6).  While profiling is enabled, workgroup 0 of every strip-kernel launch reads s_memtime (one tick per shader
- * cycle) and s_memrealtime (the constant reference clock, hipDeviceAttributeWallClockRate: 100 MHz) when it starts and when it ends and adds the differences to two device
- * counters; this call (after the launches have finished: it waits for the stream) returns *shaderMHz = reference rate x cycles / ticks over those launches (0 if none) and how many
- * launches contributed, then clears the counters.  Boxes of one pool differ in the clock they sustain under THIS kernel's load by more than they differ under a pure FMA stream;
- * lane-operations per CYCLE are what a kernel change changes.  Either pointer may be NULL. */
-rmgr_int32_t rmgr_ssim_hip_get_profile_clock(rmgr_ssim_hip_Context* ctx, double* shaderMHz, rmgr_uint64_t* launches) RMGR_NOEXCEPT;
+/* The shader clock the profiled launches really ran at (round 6).  While profiling is enabled, the first workgroups of every strip-kernel launch -- one per XCD: the
+ * dispatcher deals consecutive workgroups to the XCDs round robin -- read s_memtime (one tick per shader cycle) and s_memrealtime (the constant reference clock,
+ * hipDeviceAttributeWallClockRate: 100 MHz) when they start and when they end and add the differences to per-XCD device counters; this call (it waits for the stream)
+ * returns *shaderMHz = the mean over the XCDs of reference rate x cycles / ticks, *slowestXcdMHz = the lowest XCD's (a launch ends when its slowest XCD does) and how many
+ * launches contributed (0 and 0.0 if none), then clears the counters.  Boxes of one pool differ in the clock they sustain under THIS kernel's load by more than they
+ * differ under a pure FMA stream; lane-operations per CYCLE are what a kernel change changes.  Any pointer may be NULL. */
+rmgr_int32_t rmgr_ssim_hip_get_profile_clock(rmgr_ssim_hip_Context* ctx, double* shaderMHz, double* slowestXcdMHz, rmgr_uint64_t* launches) RMGR_NOEXCEPT;
 
 /*
  * What the vector ALUs of the context's device sustain RIGHT NOW at a forced occupancy (profiling aid; no reference counterpart; not on
  * the SSIM path).  A pure packed-fp32 instruction stream runs with its register footprint padded so that the hardware cannot place more
  * than wavesPerSimd (1, 2, 3, 4 or 8) wavefronts on a SIMD, on a grid of exactly the device's capacity at that occupancy; streamKind 0:
- * independent v_pk_fma_f32 (the issue peak at that occupancy), 1: two interleaved dependent chains of six (the blur's row sums).  Untimed
- * launches for 40 ms (the clock leaves its idle state), then `launches` (1 ... 64) timed ones of about 2 ms each with HIP events on the context's stream; *teraLaneOps
- * receives the MEDIAN launch's rate in 10^12 lane-operations per second (128 per packed instruction and wavefront).  The strip kernels are
+ * independent v_pk_fma_f32 (the issue peak at that occupancy), 1: two interleaved dependent chains of six (the blur's row sums).  Twenty untimed
+ * launches (~40 ms: the clock leaves its idle state), then `launches` (1 ... 64) timed ones of about 2 ms each between HIP events on the context's stream, all
+ * enqueued back to back and waited for once (a host-side wait between launches is an idle gap after which the clock ramps again); three such bursts, the best
+ * one counts (about one burst in four runs in a degraded mode -- same clock, the rate of one wave fewer per SIMD: profiles/r06_probe_bimodal.txt); *teraLaneOps
+ * receives the best burst's MEDIAN launch's rate in 10^12 lane-operations per second (128 per packed instruction and wavefront).  The strip kernels are
  * fp32-VALU bound and run at two (modes 0, 1, 3) or three (modes 2, 4) wavefronts per SIMD: bench.py divides their lane-operations per
  * second by this figure, measured in the same process right before and right after the timed steps, instead of by a constant measured on
- * another box.  shaderMHz (may be NULL): the shader clock the timed launches really ran at, measured on the device as rmgr_ssim_hip_get_profile_clock
- * measures the strip kernels'.  Blocking.  EINVAL for any other occupancy or stream kind.
+ * another box.  shaderMHz / slowestXcdMHz (may be NULL): the shader clock the timed launches really ran at -- mean over the XCDs, and the slowest XCD's --
+ * measured on the device as rmgr_ssim_hip_get_profile_clock measures the strip kernels'.  Blocking.  EINVAL for any other occupancy or stream kind.
  */
 rmgr_int32_t rmgr_ssim_hip_probe_valu(rmgr_ssim_hip_Context* ctx, rmgr_int32_t wavesPerSimd, rmgr_int32_t streamKind, rmgr_int32_t launches,
-                                      double* teraLaneOps, double* shaderMHz) RMGR_NOEXCEPT;
+                                      double* teraLaneOps, double* shaderMHz, double* slowestXcdMHz) RMGR_NOEXCEPT;
 
 /*
  * The synthetic test pattern the benchmark and the self-tests run on (no reference counterpart: the reference's

@@ -147,8 +147,8 @@ def load_library(path=None):
         "rmgr_ssim_hip_comm_rank_count": [vp, ctypes.POINTER(i32)],
         "rmgr_ssim_hip_enqueue_rows": [vp, PP, u32, u32, vp],
         "rmgr_ssim_hip_reduce_cells": [vp, u32, u32, u32, vp, vp],
-        "rmgr_ssim_hip_probe_valu": [vp, i32, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
-        "rmgr_ssim_hip_get_profile_clock": [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)],
+        "rmgr_ssim_hip_probe_valu": [vp, i32, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)],
+        "rmgr_ssim_hip_get_profile_clock": [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64)],
         "rmgr_ssim_hip_trim": [vp],
         "rmgr_ssim_hip_tune": [vp, u32, u32, u32, i32, ctypes.POINTER(TuneResult)],
         "rmgr_ssim_hip_clear_tuned": [vp],
@@ -483,16 +483,17 @@ class Context(object):
 
     def probe_valu(self, waves_per_simd, stream_kind=0, launches=5, with_clock=False):
         """T lane-ops/s a pure packed-fp32 stream sustains on this device right now at a forced occupancy (rmgr_ssim_hip_probe_valu);
-        with_clock: (T lane-ops/s, shader MHz the timed launches ran at)."""
-        t, mhz = ctypes.c_double(), ctypes.c_double()
-        _check("rmgr_ssim_hip_probe_valu", self.lib.rmgr_ssim_hip_probe_valu(self.handle, waves_per_simd, stream_kind, launches, ctypes.byref(t), ctypes.byref(mhz) if with_clock else None))
-        return (t.value, mhz.value) if with_clock else t.value
+        with_clock: (T lane-ops/s, mean shader MHz over the XCDs, slowest XCD's MHz) of the timed launches."""
+        t, mhz, lo = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _check("rmgr_ssim_hip_probe_valu", self.lib.rmgr_ssim_hip_probe_valu(self.handle, waves_per_simd, stream_kind, launches, ctypes.byref(t),
+                                                                             ctypes.byref(mhz) if with_clock else None, ctypes.byref(lo) if with_clock else None))
+        return (t.value, mhz.value, lo.value) if with_clock else t.value
 
     def get_profile_clock(self):
-        """(shader MHz, launches) of the profiled strip-kernel launches since the last call (rmgr_ssim_hip_get_profile_clock)."""
-        mhz, n = ctypes.c_double(), ctypes.c_uint64()
-        _check("rmgr_ssim_hip_get_profile_clock", self.lib.rmgr_ssim_hip_get_profile_clock(self.handle, ctypes.byref(mhz), ctypes.byref(n)))
-        return mhz.value, n.value
+        """(mean shader MHz over the XCDs, slowest XCD's MHz, launches) of the profiled strip-kernel launches since the last call (rmgr_ssim_hip_get_profile_clock)."""
+        mhz, lo, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_uint64()
+        _check("rmgr_ssim_hip_get_profile_clock", self.lib.rmgr_ssim_hip_get_profile_clock(self.handle, ctypes.byref(mhz), ctypes.byref(lo), ctypes.byref(n)))
+        return mhz.value, lo.value, n.value
 
     def set_profiling(self, on):
         _check("rmgr_ssim_hip_set_profiling", self.lib.rmgr_ssim_hip_set_profiling(self.handle, 1 if on else 0))

@@ -92,6 +92,8 @@ inline uint32_t cell_rows_for(uint32_t height) { return height >= 2048 ? 32u : 8
 
 // Tuning variants that force the balanced schedule of the two-column kernel: 6 with plan()'s interleave of the images in the chunk list, 7 without
 // any (round 5's list), 100 + T with T images interleaved (measurement aids; ssim_kernels.hip work_setup()).
+enum { kClockStride = 5, kClockMaxXcds = 16, kClockWords = kClockStride * kClockMaxXcds };
+
 inline bool is_balanced_variant(int variant) { return variant == 6 || variant == 7 || variant >= 100; }
 
 // Which launches run the EARLY form of the bit-exact two-column kernel by default.  Measured with both forms interleaved in
@@ -128,7 +130,8 @@ size_t partials_size(const Geometry& geo);
 //   group       > 1 when every run of `group` consecutive descriptors addresses the interleaved channels of one
 //               image pair (interleaved_group()): scheduling hint only, results do not depend on it
 // ev_begin/ev_end (optional) are recorded around the main kernel only.
-// clock (optional, profiling): 5 device uint64; workgroup 0 of the strip kernel adds its shader cycles to clock[2], its 100 MHz reference ticks to clock[3], 1 to clock[4].
+// clock (optional, profiling): kClockWords device uint64 (5 per XCD: start cycles, start ticks, sum of cycles, sum of reference ticks, launches); the first geo.xcds
+// workgroups of the strip kernel -- one per XCD -- add their own run to them.
 hipError_t launch(const Geometry& geo, int mode, int variant, int group, const PairDesc* descs_dev, const PairDesc& single,
                   double* partials, double* sums, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, bool reduce = true, uint64_t* clock = nullptr);
 
@@ -154,7 +157,7 @@ hipError_t launch_synth_pair(uint8_t* a, int64_t a_stride, uint8_t* b, int64_t b
 // Profiling aid (ssim_probe.hip): a pure packed-fp32 stream at a FORCED occupancy of waves_per_simd (1, 2, 3, 4 or 8) waves per SIMD on
 // a grid of exactly cu_count x 4 x waves_per_simd single-wave workgroups; stream_kind 0: independent v_pk_fma_f32, 1: two interleaved
 // dependent chains of six (the shape of the blur's row sums).  probe_valu_lane_ops(): the lane-operations one such launch retires.
-hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream, uint64_t* clock = nullptr);   // clock: as launch()'s
+hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int xcd_count, int iters, float* out, hipStream_t stream, uint64_t* clock = nullptr);   // clock: as launch()'s
 uint64_t probe_valu_lane_ops(int waves_per_simd, int cu_count, int iters);
 
 } // namespace ssim_hip

@@ -409,8 +409,8 @@ struct KArgs {
     uint32_t        count;        // images in this launch == gridDim.z (reading gridDim itself is a fetch from the dispatch packet)
     uint32_t        group;        // >1: runs of `group` consecutive descriptors address interleaved channels of one image pair
     double*         partials;     // [image][cell_y][cell_x]
-    uint64_t*       clock;        // profiling only (NULL otherwise): workgroup 0 adds the shader cycles (s_memtime) and the 100 MHz reference ticks (s_memrealtime) of its
-                                  // own run to clock[2], clock[3] and 1 to clock[4] -- the shader clock the kernel really ran at (clock_begin / clock_end)
+    uint64_t*       clock;        // profiling only (NULL otherwise): the first `xcds` workgroups add the shader cycles (s_memtime) and the reference ticks (s_memrealtime) of their
+                                  // own run to per-XCD counters -- the shader clock the kernel really ran at on every XCD (clock_begin / clock_end)
     float           c1, c2;
     float           gf[6];        // separable taps, fp32
     double          c1d, c2d;
@@ -433,24 +433,29 @@ struct Strip {
     uint32_t sx, sy, img;
 };
 
-// Profiling aid (rmgr_ssim_hip_set_profiling): the shader clock a launch really ran at.  Workgroup 0 notes s_memtime (one tick per shader cycle) and s_memrealtime
-// (100 MHz) when it starts and adds the differences to two device counters when it ends: frequency = 100 MHz x cycles / ticks, averaged over the profiled launches.
-// Nothing is held in registers in between (the start values wait in memory), and with clock == NULL it is one scalar branch at either end of the kernel.
+// Profiling aid (rmgr_ssim_hip_set_profiling): the shader clock a launch really ran at, per XCD.  The first `xcds` workgroups of a launch -- one per XCD: the dispatcher
+// deals consecutive workgroup ids to the XCDs round robin -- note s_memtime (one tick per shader cycle) and s_memrealtime (the constant reference clock, 100 MHz) when
+// they start and add the differences to device counters when they end: frequency of XCD x = reference rate x cycles[x] / ticks[x], accumulated over the profiled
+// launches.  Layout: CLOCK_STRIDE uint64 per XCD: start cycles, start ticks, sum of cycles, sum of ticks, launches.  Nothing is held in registers in between (the start
+// values wait in memory), and with clock == NULL it is one scalar branch at either end of the kernel.
+enum { CLOCK_STRIDE = 5 };
 __device__ __forceinline__ void clock_begin(uint64_t* clock)
 {
     const uint64_t t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) { clock[0] = t; clock[1] = r; }
+    uint64_t* c = clock + CLOCK_STRIDE * blockIdx.x;
+    if (threadIdx.x == 0) { c[0] = t; c[1] = r; }
 }
 __device__ __forceinline__ void clock_end(uint64_t* clock)
 {
     const uint64_t t = __builtin_readcyclecounter(), r = __builtin_amdgcn_s_memrealtime();
+    uint64_t* c = clock + CLOCK_STRIDE * blockIdx.x;
     if (threadIdx.x == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 2), (unsigned long long)(t - clock[0]));
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 3), (unsigned long long)(r - clock[1]));
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 4), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 2), (unsigned long long)(t - c[0]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 3), (unsigned long long)(r - c[1]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 4), 1ull);
     }
 }
-#define SSIM_CLOCKED(args) ((args).clock != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+#define SSIM_CLOCKED(args) ((args).clock != nullptr && blockIdx.x < (args).xcds && blockIdx.y == 0 && blockIdx.z == 0)
 
 // Workgroup g of `total` -> its place in the work list when each of the `xcds` XCDs (which the dispatcher deals consecutive
 // workgroup ids to, round robin) is to walk ONE contiguous share of the list: XCD k owns total / xcds entries, the first

@@ -17,32 +17,36 @@
 //   0  independent   v_pk_fma_f32 acc[j] = a * b + acc[j]: no dependency closer than 24 instructions -- the issue peak at that occupancy
 //   1  row-sum shape two interleaved dependent chains of six (t = s0 * k0; t = fma(s_i, k_i, t) ...), the blur's row sums
 #include "ssim_kernels.h"
+#include <algorithm>
 
 namespace ssim_hip {
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// W waves per SIMD -> the highest register the kernel pretends to use (512 unified registers per SIMD lane, allocated in blocks of 8)
+// W waves per SIMD -> the highest register the kernel pretends to use (512 unified registers per SIMD lane, allocated in blocks of 8).  The footprints leave
+// slack: W of them fit with room to spare, W + 1 do not.  An EXACT fit (two waves of 256: what tools/occupancy_probe.hip used) was bimodal in bench.py's process --
+// 67.5 T or 52 T (the ONE-wave rate) at the same measured clock, persistently within a call, depending on what had run before: the second 256-register block does not
+// always find a contiguous home (profiles/r06_probe_bimodal.txt).
 template <int W> __device__ __forceinline__ void pad_registers()
 {
     if constexpr (W == 1)      asm volatile("" ::: "v255", "a255");   // 512: one wave per SIMD
-    else if constexpr (W == 2) asm volatile("" ::: "v250");           // 256 >= n > 168
-    else if constexpr (W == 3) asm volatile("" ::: "v165");           // 168 >= n > 128
-    else if constexpr (W == 4) asm volatile("" ::: "v125");           // 128 >= n > 96
+    else if constexpr (W == 2) asm volatile("" ::: "v227");           // 2 x 232 = 464 (the bit-exact strip kernel's own footprint: 224...230); a third needs 696
+    else if constexpr (W == 3) asm volatile("" ::: "v150");           // 3 x 152 = 456 (MODE_SEPARABLE: 146); a fourth needs 608
+    else if constexpr (W == 4) asm volatile("" ::: "v110");           // 4 x 112 = 448; a fifth needs 560
     // W == 8: 64 or fewer, nothing to pad
 }
 
 enum { PROBE_ACCS = 24 };
 
 template <int W, int STREAM>
-__global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, float seed, uint64_t* clock)
+__global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, float seed, uint64_t* clock, unsigned xcds)
 {
     pad_registers<W>();
-    // the shader clock this launch runs at, as the strip kernels report theirs (ssim_kernels.hip clock_begin / clock_end): workgroup 0 adds its cycles and
-    // its 100 MHz reference ticks to two counters
+    // the shader clock this launch runs at on every XCD, as the strip kernels report theirs (ssim_kernels.hip clock_begin / clock_end): the first `xcds` workgroups
+    // -- one per XCD -- add their cycles and reference ticks to per-XCD counters
     uint64_t cycles0 = 0, ticks0 = 0;
-    const bool clocked = clock != nullptr && blockIdx.x == 0;
+    const bool clocked = clock != nullptr && blockIdx.x < xcds;
     if (clocked) { cycles0 = __builtin_readcyclecounter(); ticks0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int N = PROBE_ACCS;
     f2 acc[N];
@@ -74,17 +78,18 @@ __global__ __launch_bounds__(64) void probe_valu_kernel(float* out, int iters, f
     for (int j = 0; j < N; ++j) s += acc[j];
     if (s.x == 12345.678f) out[threadIdx.x] = s.x + s.y;      // never true: keeps the accumulators alive
     if (clocked && threadIdx.x == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 2), (unsigned long long)(__builtin_readcyclecounter() - cycles0));
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 3), (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ticks0));
-        atomicAdd(reinterpret_cast<unsigned long long*>(clock + 4), 1ull);
+        uint64_t* c = clock + kClockStride * blockIdx.x;
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 2), (unsigned long long)(__builtin_readcyclecounter() - cycles0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 3), (unsigned long long)(__builtin_amdgcn_s_memrealtime() - ticks0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(c + 4), 1ull);
     }
 }
 
 template <int W>
-hipError_t launch_w(int stream_kind, int blocks, float* out, int iters, hipStream_t stream, uint64_t* clock)
+hipError_t launch_w(int stream_kind, int blocks, float* out, int iters, hipStream_t stream, uint64_t* clock, unsigned xcds)
 {
-    if (stream_kind == 0) hipLaunchKernelGGL((probe_valu_kernel<W, 0>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock);
-    else                  hipLaunchKernelGGL((probe_valu_kernel<W, 1>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock);
+    if (stream_kind == 0) hipLaunchKernelGGL((probe_valu_kernel<W, 0>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock, xcds);
+    else                  hipLaunchKernelGGL((probe_valu_kernel<W, 1>), dim3(blocks), dim3(64), 0, stream, out, iters, 1.0f, clock, xcds);
     return hipGetLastError();
 }
 
@@ -96,15 +101,16 @@ uint64_t probe_valu_lane_ops(int waves_per_simd, int cu_count, int iters)
     return (uint64_t)128 * PROBE_ACCS * (uint64_t)iters * (uint64_t)cu_count * 4u * (uint64_t)waves_per_simd;
 }
 
-hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int iters, float* out, hipStream_t stream, uint64_t* clock)
+hipError_t launch_probe_valu(int waves_per_simd, int stream_kind, int cu_count, int xcd_count, int iters, float* out, hipStream_t stream, uint64_t* clock)
 {
+    const unsigned xcds = (unsigned)std::min(std::max(xcd_count, 1), (int)kClockMaxXcds);
     const int blocks = cu_count * 4 * waves_per_simd;
     switch (waves_per_simd) {
-    case 1: return launch_w<1>(stream_kind, blocks, out, iters, stream, clock);
-    case 2: return launch_w<2>(stream_kind, blocks, out, iters, stream, clock);
-    case 3: return launch_w<3>(stream_kind, blocks, out, iters, stream, clock);
-    case 4: return launch_w<4>(stream_kind, blocks, out, iters, stream, clock);
-    case 8: return launch_w<8>(stream_kind, blocks, out, iters, stream, clock);
+    case 1: return launch_w<1>(stream_kind, blocks, out, iters, stream, clock, xcds);
+    case 2: return launch_w<2>(stream_kind, blocks, out, iters, stream, clock, xcds);
+    case 3: return launch_w<3>(stream_kind, blocks, out, iters, stream, clock, xcds);
+    case 4: return launch_w<4>(stream_kind, blocks, out, iters, stream, clock, xcds);
+    case 8: return launch_w<8>(stream_kind, blocks, out, iters, stream, clock, xcds);
     default: return hipErrorInvalidValue;
     }
 }

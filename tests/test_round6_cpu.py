@@ -73,8 +73,8 @@ def test_interleaved_chunk_list_is_a_bijection():
 def test_round6_entry_points_validate_without_a_device():
     lib = ssim_amd.load_library()
     t = ctypes.c_double()
-    assert lib.rmgr_ssim_hip_probe_valu(None, 2, 0, 5, ctypes.byref(t), None) == errno.EINVAL
-    assert lib.rmgr_ssim_hip_get_profile_clock(None, ctypes.byref(t), None) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_probe_valu(None, 2, 0, 5, ctypes.byref(t), None, None) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_get_profile_clock(None, ctypes.byref(t), None, None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_tune(None, 64, 64, 1, 0, None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_clear_tuned(None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_trim_default_pool() == 0                     # nothing exists: nothing to trim
