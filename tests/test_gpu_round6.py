@@ -181,11 +181,14 @@ def test_trim_of_a_callers_context(gpu_ctx):
 
 def test_valu_probe(gpu_ctx):
     """rmgr_ssim_hip_probe_valu: a packed-fp32 stream at a forced occupancy.  On an MI355X: 60...70 T lane-ops/s at two waves per SIMD, more at
-    eight, never above the 78.6 T data-sheet peak; the dependent-chain stream is no faster than the independent one; two calls agree within 3 %."""
-    r2, r3, r8 = gpu_ctx.probe_valu(2), gpu_ctx.probe_valu(3), gpu_ctx.probe_valu(8)
-    assert 50.0 < r2 < r3 * 1.02 and r3 < r8 * 1.02 and r8 < 79.0, (r2, r3, r8)
-    assert gpu_ctx.probe_valu(2, 1) < r2 * 1.03
-    assert abs(gpu_ctx.probe_valu(2) - r2) / r2 < 0.03
+    eight, never above the 78.6 T data-sheet peak; the dependent-chain stream is no faster than the independent one.  A call is the best of three bursts because
+    a burst can run degraded (the rate of one wave fewer per SIMD at an unchanged clock: profiles/r06_probe_bimodal.txt; ~3 % of two-wave CALLS still do), so the
+    box's peak at an occupancy is taken as bench.py takes it: the best of a few calls; those agree within 3 %."""
+    peak = lambda waves, kind=0, calls=3: max(gpu_ctx.probe_valu(waves, kind) for _ in range(calls))
+    r2, r3, r8 = peak(2), peak(3), peak(8)
+    assert 55.0 < r2 < r3 * 1.02 and r3 < r8 * 1.02 and r8 < 79.0, (r2, r3, r8)
+    assert peak(2, 1) < r2 * 1.03
+    assert abs(peak(2) - r2) / r2 < 0.03
     lib = ssim_amd.load_library()
     t = ctypes.c_double()
     for waves, kind, n in ((5, 0, 5), (0, 0, 5), (2, 2, 5), (2, 0, 0), (2, 0, 65)):
@@ -193,7 +196,7 @@ def test_valu_probe(gpu_ctx):
     assert lib.rmgr_ssim_hip_probe_valu(None, 2, 0, 5, ctypes.byref(t), None, None) == errno.EINVAL
     # the shader clock the probe's timed launches ran at (workgroup 0: s_memtime cycles per s_memrealtime tick): an MI355X under load holds 1.9 ... 2.4 GHz, and at that
     # clock a SIMD retires a packed instruction every 4.0 ... 5.0 cycles at two waves
-    rate, mhz, slowest = gpu_ctx.probe_valu(2, 0, 5, with_clock=True)
+    rate, mhz, slowest = max(gpu_ctx.probe_valu(2, 0, 5, with_clock=True) for _ in range(3))
     assert 1800.0 < slowest <= mhz < 2450.0, (mhz, slowest)
     clk_per_instr = 32768.0 * mhz * 1e6 / (rate * 1e12) * 4.0
     assert 3.99 < clk_per_instr < 5.2, (rate, mhz, clk_per_instr)

@@ -84,9 +84,13 @@ intro = ("`profiles/r06_final_*`: `tools/collect_profiles.sh` on one box after t
          "launches against %.3f ms from the published line's HIP events), the exchange / host / latency probes, cold start, concurrent callers, the 30 000-case soak, the\n"
          "full-size and balanced-schedule checks.  **The published line `profiles/r06_final_bench.json` is the MEDIAN box** by `value` of the round's bench runs of the\n"
          "final library (`profiles/r06_box_spread.md`; round 5 published its fastest of seven), and every VALU fraction in it divides by the SAME box's packed-fp32\n"
-         "peak, probed in-process right before the warm-up and right after the timed steps (`rmgr_ssim_hip_probe_valu`; rounds 4-5 divided by a constant from another box).\n"
+         "peak, probed in-process before the clock-settle loop and right after the timed steps (`rmgr_ssim_hip_probe_valu`, the better sample; rounds 4-5 divided by a constant from\n"
+         "another box).  The timed launches ran at %.0f MHz (slowest XCD %.0f; `rmgr_ssim_hip_get_profile_clock`: one workgroup per XCD counts shader cycles per reference tick), the probe at %.0f MHz:\n"
+         "the SSIM kernel draws more power than a pure FMA stream and is clocked lower for it; per CLOCK the kernel issues %.1f %% of the 32768 lane-operations the chip can, the probe %.1f %% --\n"
+         "**the kernel runs at %.1f %% of the probe's per-clock rate**.\n"
          "`plan_regret` of that line (default plan / best candidate of `rmgr_ssim_hip_tune`, same run): %s. This table is generated: `tools/design_table.py`.\n\n"
-         % (head["kernel"], avg_us / 1e3, launches, head["kernel_avg_ms"], regret))
+         % (head["kernel"], avg_us / 1e3, launches, head["kernel_avg_ms"], v["shader_mhz_during_timed_launches"], v["slowest_xcd_mhz_during_timed_launches"], v["shader_mhz_during_probe"],
+            v["frac_of_issue_peak_per_clock"] * 100, v["probe_frac_of_issue_peak_per_clock"] * 100, v["frac_of_box_peak_per_clock"] * 100, regret))
 table = (intro + "| config | mode | kernel | kernel time | Mpix/s | algorithmic GB/s (% of 8 TB/s) | VALU lane-ops/s (% of the 78.6 T data sheet; % of the box's own probed peak) | CPU beside it (64 pinned threads, best run) |\n"
          "|---|---|---|---|---|---|---|---|\n" + "\n".join(rows) + "\n\n")
 
