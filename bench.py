@@ -235,6 +235,56 @@ def cpu_baseline(budget_s=10.0):
                          if kind == "reference" else "oracle/ssim_oracle.c restatement, OpenMP")}
 
 
+class PowerSampler(object):
+    """`rocm-smi --showpower --showclocks --showmaxpower --showtemp` every ~0.2 s in a side thread while the sustained leg runs: socket power against its cap, the shader clock
+    and the junction temperature the firmware reports.  Round 6 found the strip kernels POWER-bound -- 1360...1370 W of a 1400 W cap at ~2.2 GHz, where a pure FMA stream draws
+    1120 W at 2.36 GHz (tools/power_probe.py) -- and the line should say so on whatever box it runs.  Absent or unreadable rocm-smi: no `package` object, nothing else changes."""
+
+    def __init__(self):
+        import threading
+        self.samples, self.stop = [], False
+        self.thread = threading.Thread(target=self.run, daemon=True)
+
+    def start(self):
+        self.thread.start()
+
+    def run(self):
+        while not self.stop:
+            try:
+                r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--showtemp", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=10)
+                d = json.loads(r.stdout.decode())
+                self.samples.append(d[sorted(d)[0]])
+            except Exception:  # noqa: BLE001 -- a probe must not cost the bench its line
+                return
+            time.sleep(0.2)
+
+    def finish(self):
+        self.stop = True
+        self.thread.join(timeout=15)
+
+    def summary(self):
+        def series(needle):
+            out = []
+            for smp in self.samples[1:]:                 # the first sample may predate the load
+                for k, v in smp.items():
+                    if needle in k.lower():
+                        try:
+                            out.append(float(str(v).strip("()").lower().replace("mhz", "")))
+                        except ValueError:
+                            pass
+                        break
+            return sorted(out)
+        pw, cap, clk, tj = series("current socket graphics package power"), series("max graphics package power"), series("sclk clock speed"), series("sensor junction")
+        if not pw:
+            return {}
+        med = lambda v: v[len(v) // 2] if v else None
+        out = {"samples": len(pw), "power_w_median": med(pw), "power_w_max": pw[-1], "power_cap_w": med(cap), "sclk_mhz_median": med(clk), "junction_c_max": tj[-1] if tj else None,
+               "note": "rocm-smi sampled every ~0.2 s during the sustained leg (card 0): socket power against the package's cap, the firmware's shader clock, junction temperature"}
+        if med(cap):
+            out["power_frac_of_cap"] = round(med(pw) / med(cap), 4)
+        return out
+
+
 def measured_traffic(mode, workload, pairs, kernel_id):
     """(HBM bytes per launch, note) from the committed PMC measurement (profiles/traffic.json: rocprofv3 --pmc passes of
     tools/profile_target.py, FETCH_SIZE/WRITE_SIZE corrected per profiles/r01_fetch_size_calibration.md).  The file names the kernel
@@ -722,11 +772,16 @@ def main():
     if args.sustain > 0:
         n_sus = max(args.steps, int(args.sustain / max(elapsed / args.steps, 1e-6)))
         fence()
+        power = PowerSampler() if rank == 0 else None      # rocm-smi in a side thread (a child process per sample): what the package draws and clocks under this very load
+        if power:
+            power.start()
         t0 = time.perf_counter()
         for _ in range(n_sus):
             step()
         fence()
         dt_sus = time.perf_counter() - t0
+        if power:
+            power.finish()
         if dist is not None:
             t = torch.tensor([dt_sus], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -735,6 +790,8 @@ def main():
                      "mpix_s": round(float(total) * W * H * n_sus / dt_sus / 1e6, 1),
                      "vs_value": round((elapsed / args.steps) / (dt_sus / n_sus), 4),
                      "note": "the timed step repeated back to back for ~%.0f s (max over ranks): throughput at clock / thermal steady state; not `value`" % args.sustain}
+        if power and power.summary():
+            sustained["package"] = power.summary()
         last = work if dist is not None else sums_all
         if not np.array_equal(last.cpu().numpy().view(np.uint64), full_bits):
             raise SystemExit("rank %d: the sustained steps returned different sums than the gated step" % rank)
