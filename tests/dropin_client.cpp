@@ -10,6 +10,19 @@
 #include <stdlib.h>
 #include <vector>
 
+// A caller-supplied thread pool as the reference's tests write one (tests/rmgr-ssim-tests.cpp: a serial loop over the jobs); `context` counts the jobs,
+// a negative count makes the pool report failure after running them (src/ssim.cpp:1094-1097: ECHILD).
+static rmgr::ssim::int32_t serial_pool(void* context, rmgr::ssim::ThreadFct fct, void* const args[], rmgr::ssim::uint32_t threadCount, rmgr::ssim::uint32_t jobCount) RMGR_NOEXCEPT
+{
+    int* counter = static_cast<int*>(context);
+    const bool fail = *counter < 0;
+    if (threadCount == 0) return 1;
+    for (rmgr::ssim::uint32_t job = 0; job < jobCount; ++job)
+        fct(args[0], job);
+    *counter = int(jobCount);
+    return fail ? 1 : 0;
+}
+
 static bool read_file(const char* path, std::vector<unsigned char>& out, size_t n)
 {
     FILE* f = fopen(path, "rb");
@@ -65,7 +78,21 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < map.size(); ++i) mapSum += map[i];
         union { float f; unsigned u; } bits, bitsOmp;
         bits.f = ssim; bitsOmp.f = viaOmp;
-        printf("channel %d ssim 0x%08x openmp_rc %d openmp 0x%08x map_mean %.9f\n", c, bits.u, rc, bitsOmp.u, mapSum / double(map.size()));
+        // the deprecated Params block carries its thread pool (include/rmgr/ssim.h:692-697): the pool's dispatch function runs the jobs, the value is the same
+        int jobs = 0, failing = -1;
+        rmgr::ssim::Params pooled = params;
+        pooled.threadPool = serial_pool; pooled.threadPoolContext = &jobs; pooled.threadCount = 3;
+        RMGR_WARNING_PUSH()
+        RMGR_WARNING_MSVC_DISABLE(4996)
+        RMGR_WARNING_GCC_DISABLE("-Wdeprecated-declarations")
+        RMGR_WARNING_CLANG_DISABLE("-Wdeprecated-declarations")
+        union { float f; unsigned u; } bitsPool;
+        bitsPool.f = rmgr::ssim::compute_ssim(pooled);
+        pooled.threadPoolContext = &failing;
+        const int failErr = rmgr::ssim::get_errno(rmgr::ssim::compute_ssim(pooled));
+        RMGR_WARNING_POP()
+        printf("channel %d ssim 0x%08x openmp_rc %d openmp 0x%08x map_mean %.9f pool 0x%08x jobs %d failing_pool_errno %d\n", c, bits.u, rc, bitsOmp.u, mapSum / double(map.size()),
+               bitsPool.u, jobs, failErr);
     }
     return 0;
 }

@@ -546,7 +546,8 @@ def test_comm_entry_points_without_a_device(lib):
     if ssim_amd.device_count() == 0:
         t = time.time()
         rc = lib.rmgr_ssim_hip_comm_get_unique_id(ctypes.create_string_buffer(128))
-        assert rc in (errno.ECHILD, errno.ENODEV, errno.ENOSYS, errno.ETIMEDOUT) and time.time() - t < 40, rc
+        # 0: an RCCL that is already in the process (a test that imported torch ran before this one) hands out an id without touching a device
+        assert rc in (0, errno.ECHILD, errno.ENODEV, errno.ENOSYS, errno.ETIMEDOUT) and time.time() - t < 40, rc
 
 
 def test_plan_invariants_over_random_shapes():

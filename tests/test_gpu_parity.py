@@ -295,6 +295,8 @@ def test_reference_style_cxx98_client_on_gpu(tmp_path, manifest, static):
         fields = out[1 + c].split()
         assert fields[:4] == ["channel", str(c), "ssim", want], out[1 + c]
         assert fields[4:8] == ["openmp_rc", "0", "openmp", want], out[1 + c]
+        # round 6: the deprecated Params block's own thread pool is called (>= 1 job), gives the same float, and a pool that reports failure is ECHILD (src/ssim.cpp:1094-1097)
+        assert fields[10:12] == ["pool", want] and fields[12] == "jobs" and int(fields[13]) >= 1 and fields[14:16] == ["failing_pool_errno", str(errno.ECHILD)], out[1 + c]
     # the same program on a full-size frame of the reference's bbb1080 set (interleaved RGB, 1920 x 1080, JPEG quality 50)
     from conftest import _decode_rgb
     import json
