@@ -70,7 +70,7 @@ VALU_PEAK_TOPS = 78.6                 # 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz
 VALU_PEAK_F64_TOPS = 39.3             # fp64 vector: 78.6 TFLOP/s spec / 2
 # Rounds 4-5 divided every kernel by two CONSTANTS measured once, on one round-4 box (tools/occupancy_probe.hip: 74.6 / 65.1 T lane-ops/s at 8 / 2 waves
 # per SIMD) -- while the boxes of the pool differ by +-4 %.  Since round 6 the line carries the peak of the box it ran on: rmgr_ssim_hip_probe_valu (the
-# same forced-occupancy v_pk_fma_f32 stream, inside the library) runs in-process right before the warm-up and right after the timed steps; the
+# same forced-occupancy v_pk_fma_f32 stream, inside the library) runs in-process before the clock-settle loop and right after the timed steps; the
 # constants below are kept in the line for comparison with those rounds only, no fraction is computed from them any more.
 ROUND4_BOX_VALU_TOPS = {"8wave": 74.6, "2wave": 65.1, "3wave": 70.7}
 KERNEL_WAVES_PER_SIMD = {0: 2, 1: 2, 2: 3, 3: 2, 4: 3}      # what each mode's strip kernel runs at (its VGPR count; ssim_kernels.hip waves_per_simd())
