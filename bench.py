@@ -989,7 +989,8 @@ def main():
             roof.update({"traffic": traffic, "traffic_note": traffic_note,
                          "attainable_copy": attainable, "attainable_note": "device-to-device copy of 1 GiB on this box (read + write bytes / time), GB/s",
                          "kernel": kernel_name(args.mode, args.variant, want_map, headline_plan), "kernel_avg_ms": round(kernel_avg_ms, 4), "launches_timed": int(launches),
-                         "note": "kernel is fp32-VALU bound (see valu); HBM fraction reported because the metric asks for it"})
+                         "note": "HBM fraction reported because the metric asks for it; what binds this kernel is not HBM: per shader cycle it issues ~95 % of what a pure packed-FMA stream issues at its "
+                                 "occupancy (valu.frac_of_box_peak_per_clock), and its clock is set by package power (sustained.package: ~1360 W of the 1400 W cap under this load)"})
             if box_samples:
                 against_box(valu, args.mode, box_samples, kernel_clock)
             valu.update({"box_peak_2wave": max(b[2][0] for b in box_samples) if box_samples else None,
