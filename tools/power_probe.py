@@ -68,8 +68,11 @@ def main():
         keep += [da, db]
         params[i] = ssim_amd.make_params(w, h, da.ptr, 1, w, db.ptr, 1, w)
     sums = ctx.alloc(8 * n)
-    for mode, label in ((0, "SSIM kernel, MODE_EXACT, 32 x 4096^2"), (4, "SSIM kernel, MODE_SEPARABLE, 32 x 4096^2")):
+    for mode, variant, label in ((0, 0, "SSIM kernel, MODE_EXACT, 32 x 4096^2"), (4, 0, "SSIM kernel, MODE_SEPARABLE, 32 x 4096^2"), (1, 0, "SSIM kernel, MODE_FAST, 32 x 4096^2"),
+                                 (2, 0, "SSIM kernel, MODE_DOUBLE (one column per lane), 32 x 4096^2"), (0, 1, "SSIM kernel, MODE_EXACT, one column per lane (variant 1), 32 x 4096^2"),
+                                 (0, 3, "SSIM kernel, MODE_EXACT, strips with EARLY row sums (variant 3), 32 x 4096^2")):
         ctx.set_mode(mode)
+        ctx.set_tuning(0, variant)
         s = Sampler()
         ctx.set_profiling(True)
         ctx.get_profile_clock()
@@ -85,9 +88,13 @@ def main():
         mhz, lo, _ = ctx.get_profile_clock()
         ctx.set_profiling(False)
         print("%s: %.4f ms per launch = %.1f Gpix/s; the kernel measured %.0f MHz (slowest XCD %.0f)" % (label, ms / launches, n * w * h / (ms / launches) / 1e6, mhz, lo))
+        pw = sorted(float(x.get("Current Socket Graphics Package Power (W)", 0)) for x in s.samples[4:])
+        if pw and pw[len(pw) // 2] > 0:
+            print("    energy: %.2f nJ per pixel at the median %.0f W" % (pw[len(pw) // 2] * (ms / launches) * 1e-3 / (n * w * h) * 1e9, pw[len(pw) // 2]))
         summarise("  " + label, s.samples[4:])
     ctx.set_mode(0)
-    for waves in (2, 8):
+    ctx.set_tuning(0, 0)
+    for waves in (2, 3, 8):
         s = Sampler()
         t0 = time.perf_counter()
         s.start()
