@@ -86,3 +86,25 @@ def test_round6_entry_points_validate_without_a_device():
         # select_impl's path: set_mode / get_mode on the default contexts answer ENODEV without a device, and do not hang
         m = ctypes.c_int32()
         assert lib.rmgr_ssim_hip_set_mode(None, 0) == errno.ENODEV and lib.rmgr_ssim_hip_get_mode(None, ctypes.byref(m)) == errno.ENODEV
+
+
+def test_bench_package_power_summary_and_box_fractions():
+    """bench.py's round-6 helpers on canned inputs: the rocm-smi summary of the sustained leg, and the box-relative VALU fractions (best probe sample per occupancy; per clock)."""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ps = bench.PowerSampler()
+    mk = lambda p, c: {"Current Socket Graphics Package Power (W)": str(p), "Max Graphics Package Power (W)": "1400.0", "sclk clock speed:": "(%dMhz)" % c, "Temperature (Sensor junction) (C)": "57.0"}
+    ps.samples = [mk(300, 111), mk(1350, 2240), mk(1362, 2252), mk(1369, 2246)]          # the first sample predates the load and is dropped
+    out = ps.summary()
+    assert out["samples"] == 3 and out["power_w_median"] == 1362.0 and out["power_cap_w"] == 1400.0 and out["sclk_mhz_median"] == 2246.0 and out["power_frac_of_cap"] == round(1362.0 / 1400.0, 4)
+    assert bench.PowerSampler().summary() == {}                                             # no rocm-smi: no `package` object
+    valu = {"achieved": 58.0}
+    samples = [{2: (52.0, 2350.0, 2330.0), 8: (73.0, 2340.0, 2320.0)}, {2: (66.0, 2360.0, 2340.0), 8: (73.5, 2350.0, 2330.0)}]      # the first two-wave sample ran degraded
+    bench.against_box(valu, 0, samples, (2200.0, 2150.0))
+    assert valu["box_peak_2wave"] == 66.0 and valu["box_peak_8wave"] == 73.5 and valu["frac_of_box_peak_at_kernel_occupancy"] == round(58.0 / 66.0, 4)
+    k = 58.0e12 / 2200.0e6 / 32768.0
+    p = 66.0e12 / 2360.0e6 / 32768.0
+    assert valu["frac_of_issue_peak_per_clock"] == round(k, 4) and valu["frac_of_box_peak_per_clock"] == round(k / p, 4) and valu["slowest_xcd_mhz_during_timed_launches"] == 2150.0
+    v2 = {"achieved": 30.0}
+    assert bench.against_box(v2, 2, samples, (2200.0, 2150.0)) == {"achieved": 30.0}       # fp64 internals: the packed-fp32 stream is not its yardstick
