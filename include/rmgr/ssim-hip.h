@@ -59,7 +59,7 @@ extern "C" {
  *   5  round 5: MODE_FAST (1) and MODE_SEPARABLE (4) form their quotient as n * rcp(d): their values moved by <= 3 ulp (contracts unchanged); ctx == NULL calls
  *      run on a pool of default contexts and no longer serialise; Plan grew by balancedChunks / balancedChunkRows (harmless: structSize);
  *      the deadline of synchronize / destroy applies per queued all-reduce; get_default_pool, get_kernel_source_id added
- *   6  round 6: additions only -- probe_valu, tune / get_tuned, trim / trim_default_pool / get_default_pool_memory / get_memory_info; the default contexts
+ *   6  round 6: additions only -- probe_valu, get_profile_clock, tune / get_tuned / set_tuned / clear_tuned, trim / trim_default_pool / get_default_pool_memory / get_memory_info; the default contexts
  *      release staging above $RMGR_SSIM_HIP_POOL_RETAIN_MB when a call ends; a threadPool with a dispatch function IS called (one job per row band, ECHILD
  *      when it fails); Plan: balancedInterleave appended (harmless: structSize), tuning variants 7 and 100 + T; set_mode / get_mode(NULL) no longer wait for a lease */
 #define RMGR_SSIM_HIP_ABI_VERSION 6
@@ -154,7 +154,8 @@ rmgr_int32_t rmgr_ssim_hip_get_plan(const rmgr_ssim_hip_Context* ctx, rmgr_uint3
  * onto the device, fitted on 256-CU MI355X boxes; rmgr_ssim_hip_tune times the candidates that model chooses between (the default; the strips at
  * the default height with the row sums in the blur phase / a phase early; half and twice the strip height; the balanced schedule where it
  * exists; the one-column kernel for small launches) on the context's own device, under the context's arithmetic mode, on synthetic pairs of
- * the shape it allocates and frees itself (distinct images up to ~1.5 GB; withMap: dense float maps), candidates interleaved over three rounds,
+ * the shape it allocates and frees itself (distinct images up to ~1.5 GB; withMap: dense float maps; where the balanced schedule exists also the strips at its chunk
+ * height), candidates interleaved over three rounds,
  * and keeps the winner for this context's later launches of exactly that shape (width, height, count, map or not, mode) while the context is
  * on its default tuning (set_tuning(ctx, 0, 0)); a winner has to beat the default by more than 0.5 %.  Results never depend on the choice.
  * Blocking (a few dozen launches of the shape).  The reference's counterpart is a caller choosing its thread count (include/rmgr/ssim.h:528-533).
@@ -177,6 +178,20 @@ typedef struct rmgr_ssim_hip_TuneResult
 rmgr_int32_t rmgr_ssim_hip_tune(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_int32_t withMap,
                                 rmgr_ssim_hip_TuneResult* result) RMGR_NOEXCEPT;
 rmgr_int32_t rmgr_ssim_hip_clear_tuned(rmgr_ssim_hip_Context* ctx) RMGR_NOEXCEPT;
+/* The measured choices a context holds, for hosts that tune once per machine and keep the result (a serving process that restores them at start-up pays no tuning):
+ * rmgr_ssim_hip_get_tuned reads entry `index` (0, 1, ... until ENOENT) -- the launch shape (width, height, count, withMap), the arithmetic mode it was measured
+ * under and the winner as rmgr_ssim_hip_set_tuning arguments; rmgr_ssim_hip_set_tuned installs (or replaces) an entry without measuring anything, for the context's CURRENT
+ * mode (EINVAL for a shape with a zero dimension or count, a negative variant, or strip rows and variant both 0: that is the default, use clear_tuned).  Like every tuning it
+ * changes scheduling only. */
+typedef struct rmgr_ssim_hip_TunedEntry
+{
+    rmgr_uint32_t width, height, count;
+    rmgr_int32_t  withMap, mode, variant;
+    rmgr_uint32_t stripRows;
+} rmgr_ssim_hip_TunedEntry;
+rmgr_int32_t rmgr_ssim_hip_get_tuned(const rmgr_ssim_hip_Context* ctx, rmgr_uint32_t index, rmgr_ssim_hip_TunedEntry* entry) RMGR_NOEXCEPT;
+rmgr_int32_t rmgr_ssim_hip_set_tuned(rmgr_ssim_hip_Context* ctx, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_int32_t withMap,
+                                     rmgr_int32_t variant, rmgr_uint32_t stripRows) RMGR_NOEXCEPT;
 
 /*
  * compute_ssim() on HOST pointers: stages both images to HBM, runs the kernels, copies the map

@@ -50,6 +50,11 @@ class Plan(ctypes.Structure):
                 ("balancedChunks", ctypes.c_uint32), ("balancedChunkRows", ctypes.c_uint32), ("balancedInterleave", ctypes.c_uint32)]
 
 
+class TunedEntry(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("count", ctypes.c_uint32), ("withMap", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("variant", ctypes.c_int32), ("stripRows", ctypes.c_uint32)]
+
+
 class TuneResult(ctypes.Structure):
     _fields_ = [("structSize", ctypes.c_uint32), ("candidates", ctypes.c_uint32), ("bestVariant", ctypes.c_int32), ("bestStripRows", ctypes.c_uint32),
                 ("defaultMs", ctypes.c_double), ("bestMs", ctypes.c_double),
@@ -85,7 +90,7 @@ C_SYMBOLS = [
     "rmgr_ssim_hip_comm_rank_count", "rmgr_ssim_hip_comm_describe", "rmgr_ssim_hip_get_abi_version", "rmgr_ssim_hip_get_default_pool", "rmgr_ssim_hip_get_kernel_source_id",
     "rmgr_ssim_hip_enqueue_rows", "rmgr_ssim_hip_reduce_cells", "rmgr_ssim_hip_probe_valu",
     "rmgr_ssim_hip_trim", "rmgr_ssim_hip_trim_default_pool", "rmgr_ssim_hip_get_default_pool_memory", "rmgr_ssim_hip_get_memory_info",
-    "rmgr_ssim_hip_tune", "rmgr_ssim_hip_clear_tuned", "rmgr_ssim_hip_get_profile_clock",
+    "rmgr_ssim_hip_tune", "rmgr_ssim_hip_clear_tuned", "rmgr_ssim_hip_get_tuned", "rmgr_ssim_hip_set_tuned", "rmgr_ssim_hip_get_profile_clock",
 ]
 # non-inline C++ entry points of the reference, Itanium-mangled
 CXX_SYMBOLS = [
@@ -152,6 +157,8 @@ def load_library(path=None):
         "rmgr_ssim_hip_trim": [vp],
         "rmgr_ssim_hip_tune": [vp, u32, u32, u32, i32, ctypes.POINTER(TuneResult)],
         "rmgr_ssim_hip_clear_tuned": [vp],
+        "rmgr_ssim_hip_get_tuned": [vp, u32, ctypes.POINTER(TunedEntry)],
+        "rmgr_ssim_hip_set_tuned": [vp, u32, u32, u32, i32, i32, u32],
         "rmgr_ssim_hip_trim_default_pool": [],
         "rmgr_ssim_hip_get_default_pool_memory": [ctypes.POINTER(ctypes.c_uint64)] * 3,
         "rmgr_ssim_hip_get_memory_info": [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
@@ -403,6 +410,20 @@ class Context(object):
 
     def clear_tuned(self):
         _check("rmgr_ssim_hip_clear_tuned", self.lib.rmgr_ssim_hip_clear_tuned(self.handle))
+
+    def tuned(self):
+        """The measured choices the context holds: [(width, height, count, with_map, mode, variant, strip_rows), ...] (rmgr_ssim_hip_get_tuned)."""
+        out, e = [], TunedEntry()
+        while True:
+            rc = self.lib.rmgr_ssim_hip_get_tuned(self.handle, len(out), ctypes.byref(e))
+            if rc == errno.ENOENT:
+                return out
+            _check("rmgr_ssim_hip_get_tuned", rc)
+            out.append((e.width, e.height, e.count, bool(e.withMap), e.mode, e.variant, e.stripRows))
+
+    def set_tuned(self, width, height, count, with_map, variant, strip_rows):
+        """Installs a choice for a launch shape under the context's current mode without measuring (rmgr_ssim_hip_set_tuned)."""
+        _check("rmgr_ssim_hip_set_tuned", self.lib.rmgr_ssim_hip_set_tuned(self.handle, width, height, count, 1 if with_map else 0, variant, strip_rows))
 
     def trim(self):
         """Gives the context's grow-only staging back to the system (rmgr_ssim_hip_trim)."""

@@ -2187,6 +2187,12 @@ rmgr_int32_t rmgr_ssim_hip_tune(rmgr_ssim_hip_Context* c, rmgr_uint32_t width, r
         }
         const uint32_t half = std::max(cell, ((R / 2) + cell - 1) & ~(cell - 1)), twice = std::min<uint32_t>(2 * R, (height + cell - 1) & ~(cell - 1));
         const int keep = (mode == RMGR_SSIM_HIP_MODE_DOUBLE) ? 0 : (g0.strip_w == 64 ? 1 : ssim_hip::uses_early_row_sums(g0, mode, v0) ? 3 : 2);
+        if (!map && g0.n_chunks == 0) {            // where the chunks would divide the strip column evenly, the strips at the chunk height: the same partition without the segment loop
+            const ssim_hip::Geometry gb = ssim_hip::plan(width, height, count, mode, 0, 6, c->cu_count, c->xcd_count);
+            if (gb.n_chunks && gb.cells_y % gb.chunk_cells == 0) Add::one(cand, c, width, height, count, map, keep ? keep : 2, (int)(gb.chunk_cells * cell));
+        } else if (!map && g0.cells_y % g0.chunk_cells == 0) {
+            Add::one(cand, c, width, height, count, map, (mode == RMGR_SSIM_HIP_MODE_EXACT || mode == RMGR_SSIM_HIP_MODE_UNFUSED) ? 3 : 2, (int)(g0.chunk_cells * cell));
+        }
         if (half != R) Add::one(cand, c, width, height, count, map, keep, (int)half);
         if (twice != R) Add::one(cand, c, width, height, count, map, keep, (int)twice);
     } catch (...) { return ENOMEM; }
@@ -2277,6 +2283,28 @@ rmgr_int32_t rmgr_ssim_hip_clear_tuned(rmgr_ssim_hip_Context* c) RMGR_NOEXCEPT
 {
     if (!c) return EINVAL;
     c->tuned.clear();
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_get_tuned(const rmgr_ssim_hip_Context* c, rmgr_uint32_t index, rmgr_ssim_hip_TunedEntry* entry) RMGR_NOEXCEPT
+{
+    if (!c || !entry) return EINVAL;
+    if (index >= c->tuned.size()) return ENOENT;
+    const rmgr_ssim_hip_Context_::Tuned& t = c->tuned[index];
+    entry->width = t.width; entry->height = t.height; entry->count = t.count;
+    entry->withMap = t.map ? 1 : 0; entry->mode = t.mode; entry->variant = t.variant; entry->stripRows = (rmgr_uint32_t)t.strip_rows;
+    return 0;
+}
+
+rmgr_int32_t rmgr_ssim_hip_set_tuned(rmgr_ssim_hip_Context* c, rmgr_uint32_t width, rmgr_uint32_t height, rmgr_uint32_t count, rmgr_int32_t withMap,
+                                     rmgr_int32_t variant, rmgr_uint32_t stripRows) RMGR_NOEXCEPT
+{
+    if (!c || width == 0 || height == 0 || count == 0 || variant < 0 || stripRows > 0x7FFFFFFFu || (variant == 0 && stripRows == 0)) return EINVAL;
+    const bool map = withMap != 0;
+    const rmgr_ssim_hip_Context_::Tuned t = {width, height, count, c->mode, map, variant, (int)stripRows};
+    for (size_t i = 0; i < c->tuned.size(); ++i)
+        if (c->tuned[i].width == width && c->tuned[i].height == height && c->tuned[i].count == count && c->tuned[i].mode == c->mode && c->tuned[i].map == map) { c->tuned[i] = t; return 0; }
+    try { c->tuned.push_back(t); } catch (...) { return ENOMEM; }
     return 0;
 }
 

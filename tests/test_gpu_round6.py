@@ -288,7 +288,21 @@ def test_tune_measures_the_candidates_and_keeps_the_bits(gpu_ctx):
         assert all(v not in (6, 7) for v, _, _ in r["candidates"]), r
         r = gpu_ctx.tune(256, 256, 1)
         assert len(r["candidates"]) >= 2, r
+        # a host that tuned once keeps the choices: read them back, install them on another context without measuring, same bits
+        gpu_ctx.clear_tuned()
+        assert gpu_ctx.tuned() == []
+        gpu_ctx.set_tuned(w, h, n, False, 2, 64)                      # plain 64-row strips for the 24 x 1080p launch
+        gpu_ctx.set_tuned(w, h, n, False, 3, 216)                     # replaced, not duplicated
+        gpu_ctx.set_tuned(640, 480, 7, True, 1, 0)
+        assert gpu_ctx.tuned() == [(w, h, n, False, ssim_amd.MODE_EXACT, 3, 216), (640, 480, 7, True, ssim_amd.MODE_EXACT, 1, 0)]
+        tuned_bits = run()
+        gpu_ctx.clear_tuned()
+        assert np.array_equal(run(), tuned_bits)
         lib = ssim_amd.load_library()
+        e = ssim_amd.TunedEntry()
+        assert lib.rmgr_ssim_hip_get_tuned(gpu_ctx.handle, 0, ctypes.byref(e)) == errno.ENOENT
+        for bad in ((0, 8, 1, 0, 2, 8), (8, 8, 0, 0, 2, 8), (8, 8, 1, 0, -1, 8), (8, 8, 1, 0, 0, 0)):
+            assert lib.rmgr_ssim_hip_set_tuned(gpu_ctx.handle, *bad) == errno.EINVAL, bad
         assert lib.rmgr_ssim_hip_tune(gpu_ctx.handle, 0, 16, 1, 0, None) == errno.EINVAL and lib.rmgr_ssim_hip_tune(None, 16, 16, 1, 0, None) == errno.EINVAL
         assert lib.rmgr_ssim_hip_tune(gpu_ctx.handle, 300, 200, 3, 0, None) == 0          # result may be NULL
     finally:

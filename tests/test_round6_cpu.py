@@ -77,6 +77,7 @@ def test_round6_entry_points_validate_without_a_device():
     assert lib.rmgr_ssim_hip_get_profile_clock(None, ctypes.byref(t), None, None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_tune(None, 64, 64, 1, 0, None) == errno.EINVAL
     assert lib.rmgr_ssim_hip_clear_tuned(None) == errno.EINVAL
+    assert lib.rmgr_ssim_hip_get_tuned(None, 0, ctypes.byref(ssim_amd.TunedEntry())) == errno.EINVAL and lib.rmgr_ssim_hip_set_tuned(None, 64, 64, 1, 0, 2, 64) == errno.EINVAL
     assert lib.rmgr_ssim_hip_trim_default_pool() == 0                     # nothing exists: nothing to trim
     d, p, c = ssim_amd.default_pool_memory()
     assert (d, p) == (0, 0) and c == 256 << 20                            # creates nothing; the default cap
